@@ -1,0 +1,745 @@
+// Camera-calibration bundle adjustment on MI355X: handle, HIP evaluator, C ABI.
+// Replaces the body of CameraCalibration::refine between "parameters packed" and
+// "parameters unpacked" (/root/reference/modules/calib/src/calibration.cpp:359-442).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "calib_kernels.h"
+#include "common.h"
+#include "lm_driver.h"
+
+using namespace cvxk;
+
+namespace {
+
+template <class Tp>
+int dev_alloc(Tp **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    CVX_HIP(hipMalloc((void **)p, n * sizeof(Tp)));
+    return CVX_OK;
+}
+
+template <class Tp>
+int dev_upload(Tp **p, const Tp *src, size_t n, hipStream_t s) {
+    int st = dev_alloc(p, n);
+    if (st) return st;
+    if (n) CVX_HIP(hipMemcpyAsync(*p, src, n * sizeof(Tp), hipMemcpyHostToDevice, s));
+    return CVX_OK;
+}
+
+__global__ void k_fill(double *p, long long n, double v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+enum { PH_NORMAL = 0, PH_SCHUR, PH_ASSEMBLE, PH_BACKSUBST, PH_COST, PH_COUNT };
+
+}  // namespace
+
+struct cvx_calib {
+    // problem
+    int C = 0, V = 0, P = 0;
+    int64_t N = 0;
+    int fix_k3 = 1, fix_intr = 0, fix_pts = 0, device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int ncf = 0, cam_free = 0, pts_free = 0, ns = 0, ZC = 0, camcol0 = 0, ycol = 0, nt = 0, ntp = 0, nbc = 0;
+    int T = 64;
+    size_t k2_lds = 0;
+    int n_groups = 0, n_chunks = 0, n_cost_blocks = 0;
+    std::vector<int> h_cam_of_view, h_view_off;
+    // device: static
+    int *d_view_off = nullptr, *d_cam_of_view = nullptr, *d_point_id = nullptr, *d_view_id = nullptr;
+    int *d_grp_v0 = nullptr, *d_chk_row0 = nullptr, *d_chk_cam = nullptr, *d_glist = nullptr, *d_glist_off = nullptr;
+    double *d_obs_x = nullptr, *d_obs_y = nullptr;
+    // device: parameters (current / candidate)
+    double *d_intr[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr}, *d_poses[2] = {nullptr, nullptr};
+    int cur = 0;
+    // device: work
+    double *d_rt = nullptr, *d_Z = nullptr, *d_Linv = nullptr, *d_Dv = nullptr, *d_gv = nullptr, *d_s2pose = nullptr;
+    double *d_slab_pt = nullptr, *d_slab_cam = nullptr, *d_grp_scal = nullptr, *d_slab_tile = nullptr;
+    double *d_Ucx = nullptr, *d_Uxx = nullptr, *d_Gcam = nullptr;
+    double *d_E = nullptr, *h_E = nullptr;
+    size_t E_count = 0, E_scal = 0;
+    double *d_ds_emb = nullptr, *h_ds_emb = nullptr, *d_dposes = nullptr, *d_out_view = nullptr;
+    double *d_cost_partial = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
+    double *d_eval = nullptr;
+    // host copies of the shared blocks
+    std::vector<double> h_intr, h_points, h_intr_cand, h_points_cand, s2_shared, Ds, delta_s, Swork, rhs;
+    // exchange
+    cvx_allreduce_fn xfn = nullptr;
+    void *xctx = nullptr;
+    int rank = 0, nranks = 1, xdev = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[PH_COUNT][2];
+    bool ev_made = false;
+    double ph_ms[PH_COUNT] = {0, 0, 0, 0, 0};
+    long long ph_n[PH_COUNT] = {0, 0, 0, 0, 0};
+    bool ph_used[PH_COUNT] = {false, false, false, false, false};
+
+    ~cvx_calib();
+};
+
+cvx_calib::~cvx_calib() {
+    (void)hipSetDevice(device);
+    void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_chk_cam, d_glist,
+                    d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
+                    d_poses[1], d_rt, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
+                    d_slab_tile, d_Ucx, d_Uxx, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial,
+                    d_E2, d_eval};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h_E) (void)hipHostFree(h_E);
+    if (h_ds_emb) (void)hipHostFree(h_ds_emb);
+    if (h_E2) (void)hipHostFree(h_E2);
+    if (ev_made)
+        for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+namespace {
+
+inline void ph_begin(cvx_calib *h, int ph) {
+    if (h->timing) { (void)hipEventRecord(h->ev[ph][0], h->stream); }
+}
+inline void ph_end(cvx_calib *h, int ph) {
+    if (h->timing) { (void)hipEventRecord(h->ev[ph][1], h->stream); h->ph_used[ph] = true; }
+}
+// call after a stream synchronisation
+inline void ph_collect(cvx_calib *h) {
+    if (!h->timing) return;
+    for (int i = 0; i < PH_COUNT; ++i)
+        if (h->ph_used[i]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, h->ev[i][0], h->ev[i][1]) == hipSuccess) { h->ph_ms[i] += ms; h->ph_n[i]++; }
+            h->ph_used[i] = false;
+        }
+}
+
+template <int MODE>
+int launch_normal_eq(cvx_calib *h, const K2Args &a) {
+    dim3 grid(h->n_groups);
+    switch (h->T) {
+#define CVX_CASE(TT)                                                                                          \
+    case TT:                                                                                                  \
+        CVX_HIP(hipFuncSetAttribute((const void *)k_normal_eq<TT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)h->k2_lds));                                                         \
+        hipLaunchKernelGGL((k_normal_eq<TT, MODE>), grid, dim3(TT), h->k2_lds, h->stream, a);                  \
+        break;
+        CVX_CASE(64)
+        CVX_CASE(128)
+        CVX_CASE(256)
+        CVX_CASE(512)
+#undef CVX_CASE
+        default:
+            return CVX_ERR_UNSUPPORTED;
+    }
+    CVX_HIP(hipGetLastError());
+    return CVX_OK;
+}
+
+K2Args make_k2(cvx_calib *h, const cvx_damping &d) {
+    K2Args a;
+    a.view_off = h->d_view_off; a.cam_of_view = h->d_cam_of_view; a.point_id = h->d_point_id;
+    a.obs_x = h->d_obs_x; a.obs_y = h->d_obs_y;
+    a.intr = h->d_intr[h->cur]; a.points = h->d_points[h->cur]; a.rt = h->d_rt; a.s2pose = h->d_s2pose;
+    a.grp_v0 = h->d_grp_v0;
+    a.P = h->P; a.ZC = h->ZC; a.camcol0 = h->camcol0; a.ycol = h->ycol; a.cam_free = h->cam_free; a.pts_free = h->pts_free;
+    a.inv_radius = d.inv_radius; a.mu = d.mu; a.min_diag = d.min_diag; a.max_diag = d.max_diag;
+    a.Z = h->d_Z; a.Linv = h->d_Linv; a.Dv = h->d_Dv; a.gv = h->d_gv; a.s2pose_out = nullptr;
+    a.slab_pt = h->d_slab_pt; a.slab_cam = h->d_slab_cam; a.grp_scal = h->d_grp_scal;
+    return a;
+}
+
+int launch_pose_prepare(cvx_calib *h, const double *poses) {
+    if (h->V == 0) return CVX_OK;
+    hipLaunchKernelGGL(k_pose_prepare, dim3((h->V + 127) / 128), dim3(128), 0, h->stream, poses, h->d_rt, h->V);
+    CVX_HIP(hipGetLastError());
+    return CVX_OK;
+}
+
+// linearise at the current point and bring E to the host.  with_schur = false leaves S = U.
+int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_scale) {
+    int st = launch_pose_prepare(h, h->d_poses[h->cur]);
+    if (st) return st;
+    K2Args a = make_k2(h, d);
+    ph_begin(h, PH_NORMAL);
+    if (init_mode) {
+        a.s2pose_out = write_scale ? h->d_s2pose : nullptr;
+        st = launch_normal_eq<1>(h, a);
+    } else {
+        st = launch_normal_eq<0>(h, a);
+    }
+    if (st) return st;
+    ph_end(h, PH_NORMAL);
+    const bool schur = !init_mode && h->ns > 0;
+    if (schur) {
+        K3Args k;
+        k.Z = h->d_Z; k.chk_row0 = h->d_chk_row0; k.slab = h->d_slab_tile;
+        k.ZC = h->ZC; k.n_chunks = h->n_chunks; k.nt = h->nt; k.ntp = h->ntp; k.nbc = h->nbc;
+        const int blocks = 8 * ((h->n_chunks + 7) / 8) * h->nbc;
+        ph_begin(h, PH_SCHUR);
+        hipLaunchKernelGGL(k_schur_syrk, dim3(blocks), dim3(256), 0, h->stream, k);
+        CVX_HIP(hipGetLastError());
+        ph_end(h, PH_SCHUR);
+    }
+    ph_begin(h, PH_ASSEMBLE);
+    double *scal = h->d_E + h->E_scal;
+    CVX_HIP(hipMemsetAsync(scal, 0, (2 + 2 * (size_t)h->nranks) * sizeof(double), h->stream));
+    {
+        URArgs u;
+        u.slab_pt = h->d_slab_pt; u.slab_cam = h->d_slab_cam; u.grp_scal = h->d_grp_scal;
+        u.glist = h->d_glist; u.glist_off = h->d_glist_off;
+        u.n_groups = h->n_groups; u.C = h->C; u.P = h->P; u.cam_free = h->cam_free; u.pts_free = h->pts_free;
+        u.Ucx = h->d_Ucx; u.Uxx = h->d_Uxx; u.Gcam = h->d_Gcam;
+        u.out_sum = scal; u.out_bad = scal + 1; u.out_gmax = scal + 2 + h->rank; u.out_dmax = scal + 2 + h->nranks + h->rank;
+        long long n = 1 + (long long)h->C * 256;
+        if (h->cam_free && h->pts_free) n += (long long)h->C * h->P * 27;
+        if (h->pts_free) n += (long long)h->P * 9;
+        hipLaunchKernelGGL(k_ureduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, u);
+        CVX_HIP(hipGetLastError());
+    }
+    if (h->ns > 0) {
+        AsmArgs s;
+        s.slab = h->d_slab_tile; s.Ucx = h->d_Ucx; s.Uxx = h->d_Uxx; s.Gcam = h->d_Gcam; s.chk_cam = h->d_chk_cam;
+        s.ns = h->ns; s.C = h->C; s.P = h->P; s.ncf = h->ncf; s.fix_k3 = h->fix_k3; s.pts_free = h->pts_free;
+        s.ZC = h->ZC; s.camcol0 = h->camcol0; s.ycol = h->ycol; s.nt = h->nt; s.ntp = h->ntp;
+        s.n_chunks = schur ? h->n_chunks : 0;
+        s.E = h->d_E;
+        const long long n = (long long)h->ns * h->ns + h->ns;
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, s);
+        CVX_HIP(hipGetLastError());
+    }
+    ph_end(h, PH_ASSEMBLE);
+    // exchange step (view-sharded runs): one all-reduce of [S | gred | gs | diagU | scalars]
+    if (h->nranks > 1 && h->xfn && h->xdev) {
+        if (h->xfn(h->xctx, h->d_E, h->E_count, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
+    }
+    CVX_HIP(hipMemcpyAsync(h->h_E, h->d_E, h->E_count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    ph_collect(h);
+    if (h->nranks > 1 && h->xfn && !h->xdev) {
+        if (h->xfn(h->xctx, h->h_E, h->E_count, 0, nullptr)) return CVX_ERR_EXCHANGE;
+    }
+    return CVX_OK;
+}
+
+struct HostLin {
+    double cost, gmax, dmax, nbad;
+    const double *S, *gred, *gs, *diagU;
+};
+
+HostLin read_E(cvx_calib *h) {
+    HostLin r;
+    const size_t nn = (size_t)h->ns * h->ns;
+    r.S = h->h_E; r.gred = h->h_E + nn; r.gs = r.gred + h->ns; r.diagU = r.gs + h->ns;
+    const double *scal = h->h_E + h->E_scal;
+    r.cost = 0.5 * scal[0];
+    r.nbad = scal[1];
+    double gm = 0, dm = 0;
+    for (int q = 0; q < h->nranks; ++q) { gm = std::max(gm, scal[2 + q]); dm = std::max(dm, scal[2 + h->nranks + q]); }
+    for (int i = 0; i < h->ns; ++i) { gm = std::max(gm, std::fabs(r.gs[i])); dm = std::max(dm, r.diagU[i]); }
+    r.gmax = gm; r.dmax = dm;
+    return r;
+}
+
+// index of shared parameter i in the host intrinsics / points arrays
+inline double *shared_ptr_of(cvx_calib *h, std::vector<double> &intr, std::vector<double> &pts, int i) {
+    const int ncam = h->C * h->ncf;
+    if (i < ncam) {
+        const int c = i / h->ncf, k = i % h->ncf;
+        const int kk = (h->fix_k3 && k >= 6) ? k + 1 : k;
+        return &intr[9 * c + kk];
+    }
+    return &pts[i - ncam];
+}
+
+class CalibEvaluator : public cvx::Evaluator {
+public:
+    explicit CalibEvaluator(cvx_calib *h_) : h(h_) {}
+    cvx_calib *h;
+    // extra outputs of the last try_step, for cvx_calib_linear_step
+    bool keep_dposes = false;
+
+    cvx::InitInfo init(bool jacobi) override {
+        cvx::InitInfo out;
+        if (!jacobi) {
+            const long long n = 6LL * h->V;
+            if (n) hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_s2pose, n, 1.0);
+        }
+        cvx_damping d0 = {0, 0, 0, 0};
+        out.status = linearize(h, d0, true, jacobi);
+        if (out.status) return out;
+        HostLin L = read_E(h);
+        for (int i = 0; i < h->ns; ++i) {
+            if (jacobi) { const double s = 1.0 / (1.0 + std::sqrt(L.diagU[i])); h->s2_shared[i] = s * s; }
+            else h->s2_shared[i] = 1.0;
+        }
+        out.cost = L.cost; out.grad_max = L.gmax; out.diag_max = L.dmax;
+        return out;
+    }
+
+    cvx::StepInfo try_step(const cvx_damping &d, double gtol, bool gradient_only) override {
+        cvx::StepInfo out;
+        out.status = linearize(h, d, false, false);
+        if (out.status) return out;
+        HostLin L = read_E(h);
+        out.cost = L.cost; out.grad_max = L.gmax;
+        if (L.gmax <= gtol) { out.grad_converged = true; return out; }
+        if (gradient_only) return out;
+        const int ns = h->ns;
+        // norms of the current point
+        double xs2 = 0, fs2 = 0;
+        if (h->cam_free) {
+            for (double v : h->h_intr) xs2 += v * v;
+            for (int c = 0; c < h->C; ++c)
+                for (int k = 0; k < 9; ++k)
+                    if (!(h->fix_k3 && k == 6)) fs2 += h->h_intr[9 * c + k] * h->h_intr[9 * c + k];
+        }
+        if (h->pts_free) for (double v : h->h_points) { xs2 += v * v; fs2 += v * v; }
+        if (L.nbad > 0) { out.ok = false; return out; }
+        // damped reduced system on the host
+        bool solved = true;
+        if (ns > 0) {
+            std::memcpy(h->Swork.data(), L.S, sizeof(double) * (size_t)ns * ns);
+            for (int i = 0; i < ns; ++i) {
+                const double s2 = h->s2_shared[i];
+                double c = s2 * L.diagU[i];
+                c = std::min(std::max(c, d.min_diag), d.max_diag);
+                h->Ds[i] = c * d.inv_radius / s2 + d.mu;
+                h->Swork[(size_t)i * ns + i] += h->Ds[i];
+                h->rhs[i] = -L.gred[i];
+            }
+            if (want_S) std::memcpy(want_S, h->Swork.data(), sizeof(double) * (size_t)ns * ns);
+            solved = cvx::host_cholesky_solve(ns, h->Swork.data(), h->rhs.data());
+            if (solved) for (int i = 0; i < ns; ++i) solved = solved && std::isfinite(h->rhs[i]);
+        }
+        if (!solved) { out.ok = false; return out; }
+        for (int i = 0; i < ns; ++i) h->delta_s[i] = h->rhs[i];
+        // candidate shared parameters, embedded step per camera
+        h->h_intr_cand = h->h_intr; h->h_points_cand = h->h_points;
+        double ms = 0, ss2 = 0;
+        for (int i = 0; i < ns; ++i) {
+            const double ds = h->delta_s[i];
+            *shared_ptr_of(h, h->h_intr_cand, h->h_points_cand, i) += ds;
+            ms += ds * (h->Ds[i] * ds - L.gs[i]);
+            ss2 += ds * ds;
+        }
+        const int ncam = h->C * h->ncf;
+        std::memset(h->h_ds_emb, 0, sizeof(double) * (size_t)h->C * h->ZC);
+        for (int c = 0; c < h->C; ++c) {
+            double *e = h->h_ds_emb + (size_t)c * h->ZC;
+            if (h->pts_free) for (int q = 0; q < 3 * h->P; ++q) e[q] = h->delta_s[ncam + q];
+            for (int k = 0; k < h->ncf; ++k) {
+                const int kk = (h->fix_k3 && k >= 6) ? k + 1 : k;
+                e[h->camcol0 + kk] = h->delta_s[c * h->ncf + k];
+            }
+            e[h->ycol] = 1.0;
+        }
+        const int nxt = 1 - h->cur;
+        int st = upload_candidate(nxt);
+        if (st) { out.status = st; return out; }
+        ph_begin(h, PH_BACKSUBST);
+        if (h->V > 0) {
+            hipLaunchKernelGGL(k_backsubst, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, h->d_Z, h->d_Linv, h->d_Dv,
+                               h->d_gv, h->d_ds_emb, h->d_cam_of_view, h->d_poses[h->cur], h->d_poses[nxt],
+                               keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V, h->ZC);
+            if (hipGetLastError() != hipSuccess) { out.status = CVX_ERR_HIP; return out; }
+        }
+        ph_end(h, PH_BACKSUBST);
+        st = candidate_cost(nxt);
+        if (st) { out.status = st; return out; }
+        out.cand_cost = 0.5 * h->h_E2[0];
+        out.model_change = 0.5 * (h->h_E2[1] + ms);
+        out.step_norm2 = h->h_E2[2] + ss2;
+        out.x_norm2 = h->h_E2[3] + xs2;
+        out.free_norm2 = h->h_E2[3] + fs2;
+        out.ok = std::isfinite(out.model_change) && std::isfinite(out.step_norm2);
+        return out;
+    }
+
+    int accept() override {
+        h->cur = 1 - h->cur;
+        h->h_intr = h->h_intr_cand;
+        h->h_points = h->h_points_cand;
+        return CVX_OK;
+    }
+
+    double *want_S = nullptr;
+
+private:
+    int upload_candidate(int nxt) {
+        CVX_HIP(hipMemcpyAsync(h->d_ds_emb, h->h_ds_emb, sizeof(double) * (size_t)h->C * h->ZC, hipMemcpyHostToDevice, h->stream));
+        CVX_HIP(hipMemcpyAsync(h->d_intr[nxt], h->h_intr_cand.data(), sizeof(double) * 9 * h->C, hipMemcpyHostToDevice, h->stream));
+        CVX_HIP(hipMemcpyAsync(h->d_points[nxt], h->h_points_cand.data(), sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
+        return CVX_OK;
+    }
+    int candidate_cost(int nxt) {
+        int st = launch_pose_prepare(h, h->d_poses[nxt]);
+        if (st) return st;
+        ph_begin(h, PH_COST);
+        hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
+                           h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[nxt], h->d_points[nxt], h->d_rt,
+                           (long long)h->N, h->d_cost_partial);
+        CVX_HIP(hipGetLastError());
+        ph_end(h, PH_COST);
+        hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(256), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
+                           h->d_out_view, h->V, h->d_E2);
+        CVX_HIP(hipGetLastError());
+        if (h->nranks > 1 && h->xfn && h->xdev) {
+            if (h->xfn(h->xctx, h->d_E2, 4, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
+        }
+        CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CVX_HIP(hipStreamSynchronize(h->stream));
+        ph_collect(h);
+        if (h->nranks > 1 && h->xfn && !h->xdev) {
+            if (h->xfn(h->xctx, h->h_E2, 4, 0, nullptr)) return CVX_ERR_EXCHANGE;
+        }
+        return CVX_OK;
+    }
+};
+
+int alloc_exchange(cvx_calib *h) {
+    if (h->d_E) { (void)hipFree(h->d_E); h->d_E = nullptr; }
+    if (h->h_E) { (void)hipHostFree(h->h_E); h->h_E = nullptr; }
+    h->E_scal = (size_t)h->ns * h->ns + 3 * (size_t)h->ns;
+    h->E_count = h->E_scal + 2 + 2 * (size_t)h->nranks;
+    int st = dev_alloc(&h->d_E, h->E_count);
+    if (st) return st;
+    CVX_HIP(hipMemsetAsync(h->d_E, 0, h->E_count * sizeof(double), h->stream));
+    CVX_HIP(hipHostMalloc((void **)&h->h_E, h->E_count * sizeof(double), hipHostMallocDefault));
+    return CVX_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
+    if (!d || !out) return CVX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (d->n_cameras < 1 || d->n_cameras > CVX_MAX_CAMERAS || d->n_views < 0 || d->n_points < 1 || d->n_obs < 0)
+        return CVX_ERR_INVALID_ARG;
+    if (!d->cam_of_view || !d->view_off || (d->n_obs > 0 && (!d->point_id || !d->obs_x || !d->obs_y)))
+        return CVX_ERR_INVALID_ARG;
+    if (d->n_points > CVX_MAX_POINTS) return CVX_ERR_UNSUPPORTED;
+    const int V = d->n_views, P = d->n_points, C = d->n_cameras;
+    if (d->view_off[0] != 0 || d->view_off[V] != d->n_obs) return CVX_ERR_INVALID_ARG;
+    int maxn = 0;
+    {
+        std::vector<int> stamp(P, -1);
+        for (int v = 0; v < V; ++v) {
+            if (d->cam_of_view[v] < 0 || d->cam_of_view[v] >= C) return CVX_ERR_INVALID_ARG;
+            const int n = d->view_off[v + 1] - d->view_off[v];
+            if (n < 0) return CVX_ERR_INVALID_ARG;
+            maxn = std::max(maxn, n);
+            for (int o = d->view_off[v]; o < d->view_off[v + 1]; ++o) {
+                const int pid = d->point_id[o];
+                if (pid < 0 || pid >= P) return CVX_ERR_INVALID_ARG;
+                if (stamp[pid] == v) return CVX_ERR_DUPLICATE_MARKER;
+                stamp[pid] = v;
+            }
+        }
+    }
+    if (maxn > CVX_MAX_MARKERS_PER_VIEW) return CVX_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        cvx::set_last_error("no HIP device visible");
+        return CVX_ERR_NO_DEVICE;
+    }
+    if (d->device < 0 || d->device >= ndev) return CVX_ERR_NO_DEVICE;
+    CVX_HIP(hipSetDevice(d->device));
+
+    cvx_calib *h = new cvx_calib;
+    std::unique_ptr<cvx_calib> guard(h);
+    h->C = C; h->V = V; h->P = P; h->N = d->n_obs;
+    h->fix_k3 = d->fix_k3 ? 1 : 0; h->fix_intr = d->fix_intrinsics ? 1 : 0; h->fix_pts = d->fix_points ? 1 : 0;
+    h->device = d->device;
+    if (d->stream) h->stream = (hipStream_t)d->stream;
+    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    h->cam_free = h->fix_intr ? 0 : 1;
+    h->pts_free = h->fix_pts ? 0 : 1;
+    h->ncf = h->fix_intr ? 0 : (h->fix_k3 ? 8 : 9);
+    h->ns = C * h->ncf + (h->pts_free ? 3 * P : 0);
+    h->camcol0 = h->pts_free ? 3 * P : 0;
+    h->ycol = h->camcol0 + (h->cam_free ? 9 : 0);
+    h->ZC = ((h->ycol + 1 + ZTILE - 1) / ZTILE) * ZTILE;
+    h->nt = h->ZC / ZTILE;
+    h->ntp = h->nt * (h->nt + 1) / 2;
+    h->nbc = (h->ntp + 3) / 4;
+    h->T = maxn <= 64 ? 64 : maxn <= 128 ? 128 : maxn <= 256 ? 256 : 512;
+    const int W = h->T / 64;
+    h->k2_lds = sizeof(double) * ((size_t)P * PT_ACC + (size_t)W * 64 * AROW + (size_t)W * 256 + 256);
+    if (h->k2_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
+    h->h_cam_of_view.assign(d->cam_of_view, d->cam_of_view + V);
+    h->h_view_off.assign(d->view_off, d->view_off + V + 1);
+
+    // groups (K2 workgroups) and chunks (K3 row ranges): contiguous views of one camera
+    std::vector<int> grp_v0, grp_cam, chk_row0, chk_cam;
+    {
+        const int vpg = std::max(1, (V + 1023) / 1024);
+        int v = 0;
+        while (v < V) {
+            const int c = d->cam_of_view[v];
+            int e = v;
+            while (e < V && e - v < vpg && d->cam_of_view[e] == c) ++e;
+            grp_v0.push_back(v); grp_cam.push_back(c);
+            v = e;
+        }
+        grp_v0.push_back(V);
+        h->n_groups = (int)grp_cam.size();
+        const int target_chunks = std::max(1, 2048 / std::max(1, h->ntp));
+        const int gpc = std::max(1, (h->n_groups + target_chunks - 1) / target_chunks);
+        int g = 0;
+        while (g < h->n_groups) {
+            const int c = grp_cam[g];
+            int e = g;
+            while (e < h->n_groups && e - g < gpc && grp_cam[e] == c) ++e;
+            chk_row0.push_back(6 * grp_v0[g]); chk_cam.push_back(c);
+            g = e;
+        }
+        chk_row0.push_back(6 * V);
+        h->n_chunks = (int)chk_cam.size();
+    }
+    std::vector<int> glist(h->n_groups), glist_off(C + 1, 0);
+    for (int g = 0; g < h->n_groups; ++g) glist_off[grp_cam[g] + 1]++;
+    for (int c = 0; c < C; ++c) glist_off[c + 1] += glist_off[c];
+    {
+        std::vector<int> pos(glist_off.begin(), glist_off.end() - 1);
+        for (int g = 0; g < h->n_groups; ++g) glist[pos[grp_cam[g]]++] = g;
+    }
+    std::vector<int> view_id((size_t)h->N);
+    for (int v = 0; v < V; ++v)
+        for (int o = d->view_off[v]; o < d->view_off[v + 1]; ++o) view_id[o] = v;
+
+    hipStream_t s = h->stream;
+    int st;
+#define CVX_TRY(x) do { st = (x); if (st) return st; } while (0)
+    CVX_TRY(dev_upload(&h->d_view_off, d->view_off, (size_t)V + 1, s));
+    CVX_TRY(dev_upload(&h->d_cam_of_view, d->cam_of_view, (size_t)V, s));
+    CVX_TRY(dev_upload(&h->d_point_id, d->point_id, (size_t)h->N, s));
+    CVX_TRY(dev_upload(&h->d_view_id, view_id.data(), (size_t)h->N, s));
+    CVX_TRY(dev_upload(&h->d_obs_x, d->obs_x, (size_t)h->N, s));
+    CVX_TRY(dev_upload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
+    CVX_TRY(dev_upload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
+    CVX_TRY(dev_upload(&h->d_chk_row0, chk_row0.data(), chk_row0.size(), s));
+    CVX_TRY(dev_upload(&h->d_chk_cam, chk_cam.data(), chk_cam.size(), s));
+    CVX_TRY(dev_upload(&h->d_glist, glist.data(), glist.size(), s));
+    CVX_TRY(dev_upload(&h->d_glist_off, glist_off.data(), glist_off.size(), s));
+    for (int k = 0; k < 2; ++k) {
+        CVX_TRY(dev_alloc(&h->d_intr[k], 9 * (size_t)C));
+        CVX_TRY(dev_alloc(&h->d_points[k], 3 * (size_t)P));
+        CVX_TRY(dev_alloc(&h->d_poses[k], 6 * (size_t)V));
+        CVX_HIP(hipMemsetAsync(h->d_intr[k], 0, 9 * (size_t)C * sizeof(double), s));
+        CVX_HIP(hipMemsetAsync(h->d_points[k], 0, 3 * (size_t)P * sizeof(double), s));
+        if (V) CVX_HIP(hipMemsetAsync(h->d_poses[k], 0, 6 * (size_t)V * sizeof(double), s));
+    }
+    CVX_TRY(dev_alloc(&h->d_rt, (size_t)V * RT_STRIDE));
+    const size_t zn = ((size_t)6 * V + 8) * h->ZC;
+    CVX_TRY(dev_alloc(&h->d_Z, zn));
+    CVX_HIP(hipMemsetAsync(h->d_Z, 0, zn * sizeof(double), s));
+    CVX_TRY(dev_alloc(&h->d_Linv, 21 * (size_t)V));
+    CVX_TRY(dev_alloc(&h->d_Dv, 6 * (size_t)V));
+    CVX_TRY(dev_alloc(&h->d_gv, 6 * (size_t)V));
+    CVX_TRY(dev_alloc(&h->d_s2pose, 6 * (size_t)V));
+    if (V) hipLaunchKernelGGL(k_fill, dim3((unsigned)((6LL * V + 255) / 256)), dim3(256), 0, s, h->d_s2pose, 6LL * V, 1.0);
+    CVX_TRY(dev_alloc(&h->d_slab_pt, (size_t)h->n_groups * P * PT_ACC));
+    CVX_HIP(hipMemsetAsync(h->d_slab_pt, 0, std::max<size_t>(1, (size_t)h->n_groups * P * PT_ACC) * sizeof(double), s));
+    CVX_TRY(dev_alloc(&h->d_slab_cam, (size_t)h->n_groups * 256));
+    CVX_TRY(dev_alloc(&h->d_grp_scal, (size_t)h->n_groups * 4));
+    CVX_TRY(dev_alloc(&h->d_slab_tile, (size_t)h->n_chunks * h->ntp * ZTILE * ZTILE));
+    CVX_TRY(dev_alloc(&h->d_Ucx, (size_t)C * P * 27));
+    CVX_TRY(dev_alloc(&h->d_Uxx, (size_t)P * 9));
+    CVX_TRY(dev_alloc(&h->d_Gcam, (size_t)C * 256));
+    CVX_TRY(alloc_exchange(h));
+    CVX_TRY(dev_alloc(&h->d_ds_emb, (size_t)C * h->ZC));
+    CVX_HIP(hipHostMalloc((void **)&h->h_ds_emb, sizeof(double) * (size_t)C * h->ZC, hipHostMallocDefault));
+    CVX_TRY(dev_alloc(&h->d_dposes, 6 * (size_t)V));
+    CVX_TRY(dev_alloc(&h->d_out_view, 3 * (size_t)V));
+    h->n_cost_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (h->N + 255) / 256));
+    CVX_TRY(dev_alloc(&h->d_cost_partial, (size_t)h->n_cost_blocks));
+    CVX_TRY(dev_alloc(&h->d_E2, 8));
+    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 8 * sizeof(double), hipHostMallocDefault));
+#undef CVX_TRY
+    h->h_intr.assign(9 * (size_t)C, 0.0); h->h_points.assign(3 * (size_t)P, 0.0);
+    h->h_intr_cand = h->h_intr; h->h_points_cand = h->h_points;
+    const size_t nsz = std::max(1, h->ns);
+    h->s2_shared.assign(nsz, 1.0); h->Ds.assign(nsz, 0.0); h->delta_s.assign(nsz, 0.0);
+    h->Swork.assign(nsz * nsz, 0.0); h->rhs.assign(nsz, 0.0);
+    for (int i = 0; i < PH_COUNT; ++i) {
+        CVX_HIP(hipEventCreate(&h->ev[i][0]));
+        CVX_HIP(hipEventCreate(&h->ev[i][1]));
+    }
+    h->ev_made = true;
+    CVX_HIP(hipStreamSynchronize(s));
+    *out = guard.release();
+    return CVX_OK;
+}
+
+extern "C" void cvx_calib_destroy(cvx_calib *h) { delete h; }
+
+extern "C" int cvx_calib_set_params(cvx_calib *h, const double *intr, const double *poses, const double *points) {
+    if (!h || !intr || !points || (h->V > 0 && !poses)) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    h->h_intr.assign(intr, intr + 9 * (size_t)h->C);
+    h->h_points.assign(points, points + 3 * (size_t)h->P);
+    const int c = h->cur;
+    CVX_HIP(hipMemcpyAsync(h->d_intr[c], intr, sizeof(double) * 9 * h->C, hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipMemcpyAsync(h->d_points[c], points, sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
+    if (h->V) CVX_HIP(hipMemcpyAsync(h->d_poses[c], poses, sizeof(double) * 6 * (size_t)h->V, hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_get_params(cvx_calib *h, double *intr, double *poses, double *points) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    if (intr) std::memcpy(intr, h->h_intr.data(), sizeof(double) * 9 * h->C);
+    if (points) std::memcpy(points, h->h_points.data(), sizeof(double) * 3 * h->P);
+    if (poses && h->V) {
+        CVX_HIP(hipMemcpyAsync(poses, h->d_poses[h->cur], sizeof(double) * 6 * (size_t)h->V, hipMemcpyDeviceToHost, h->stream));
+        CVX_HIP(hipStreamSynchronize(h->stream));
+    }
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_num_shared(const cvx_calib *h) { return h ? h->ns : -1; }
+
+extern "C" int cvx_calib_cost(cvx_calib *h, double *cost) {
+    if (!h || !cost) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    int st = launch_pose_prepare(h, h->d_poses[h->cur]);
+    if (st) return st;
+    hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
+                       h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur], h->d_points[h->cur], h->d_rt,
+                       (long long)h->N, h->d_cost_partial);
+    CVX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(256), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
+                       h->d_out_view, 0, h->d_E2);
+    CVX_HIP(hipGetLastError());
+    CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    *cost = 0.5 * h->h_E2[0];
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_evaluate_device(cvx_calib *h, void **device_buffer) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    if (!h->d_eval) {
+        int st = dev_alloc(&h->d_eval, 38 * (size_t)h->N);
+        if (st) return st;
+    }
+    int st = launch_pose_prepare(h, h->d_poses[h->cur]);
+    if (st) return st;
+    if (h->N > 0) {
+        hipLaunchKernelGGL(k_eval, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->d_view_id,
+                           h->d_cam_of_view, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur],
+                           h->d_points[h->cur], h->d_rt, (long long)h->N, h->d_eval);
+        CVX_HIP(hipGetLastError());
+    }
+    if (device_buffer) *device_buffer = h->d_eval;
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_evaluate(cvx_calib *h, double *cost, double *r, double *Jc, double *Jp, double *Jx) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    int st = cvx_calib_evaluate_device(h, nullptr);
+    if (st) return st;
+    const size_t N = (size_t)h->N;
+    std::vector<double> buf(38 * N);
+    if (N) CVX_HIP(hipMemcpyAsync(buf.data(), h->d_eval, sizeof(double) * 38 * N, hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    double s = 0;
+    for (size_t o = 0; o < N; ++o) {
+        const double r0 = buf[o], r1 = buf[N + o];
+        s += r0 * r0 + r1 * r1;
+        if (r) { r[2 * o] = r0; r[2 * o + 1] = r1; }
+        if (Jc) for (int i = 0; i < 18; ++i) Jc[18 * o + i] = buf[(2 + i) * N + o];
+        if (Jp) for (int i = 0; i < 12; ++i) Jp[12 * o + i] = buf[(20 + i) * N + o];
+        if (Jx) for (int i = 0; i < 6; ++i) Jx[6 * o + i] = buf[(32 + i) * N + o];
+    }
+    if (cost) *cost = 0.5 * s;
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_init_scaling(cvx_calib *h, int enable) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    CalibEvaluator ev(h);
+    return ev.init(enable != 0).status;
+}
+
+extern "C" int cvx_calib_linear_step(cvx_calib *h, const cvx_damping *d, double *S, double *gred,
+                                     double *delta_shared, double *delta_poses, double *cost,
+                                     double *cand_cost, double *model_change) {
+    if (!h || !d) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    CalibEvaluator ev(h);
+    ev.keep_dposes = true;
+    ev.want_S = S;
+    cvx::StepInfo s = ev.try_step(*d, -1.0, false);
+    if (s.status) return s.status;
+    if (cost) *cost = s.cost;
+    if (gred) std::memcpy(gred, h->h_E + (size_t)h->ns * h->ns, sizeof(double) * h->ns);
+    if (!s.ok) return CVX_ERR_NUMERIC;
+    if (delta_shared) std::memcpy(delta_shared, h->delta_s.data(), sizeof(double) * h->ns);
+    if (delta_poses && h->V) {
+        CVX_HIP(hipMemcpyAsync(delta_poses, h->d_dposes, sizeof(double) * 6 * (size_t)h->V, hipMemcpyDeviceToHost, h->stream));
+        CVX_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (cand_cost) *cand_cost = s.cand_cost;
+    if (model_change) *model_change = s.model_change;
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks,
+                                      int device_buffers) {
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    h->xfn = fn; h->xctx = ctx; h->rank = rank; h->nranks = nranks; h->xdev = device_buffers ? 1 : 0;
+    int st = alloc_exchange(h);
+    if (st) return st;
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *summary) {
+    if (!h || !opt || !summary) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    CalibEvaluator ev(h);
+    return cvx::lm_minimize(ev, *opt, *summary);
+}
+
+extern "C" double cvx_calib_refine_return(double total_cost, int64_t n_obs_total) {
+    return std::sqrt(total_cost / (2.0 * (double)n_obs_total));
+}
+
+extern "C" int cvx_calib_enable_timing(cvx_calib *h, int enable) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    h->timing = enable != 0;
+    for (int i = 0; i < PH_COUNT; ++i) { h->ph_ms[i] = 0; h->ph_n[i] = 0; h->ph_used[i] = false; }
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_phase_times(cvx_calib *h, double ms[16]) {
+    if (!h || !ms) return CVX_ERR_INVALID_ARG;
+    for (int i = 0; i < PH_COUNT; ++i) { ms[i] = h->ph_ms[i]; ms[8 + i] = (double)h->ph_n[i]; }
+    for (int i = PH_COUNT; i < 8; ++i) { ms[i] = 0; ms[8 + i] = 0; }
+    return CVX_OK;
+}
+
+// geometry the bench needs to state algorithmic work: [0] ZC, [1] ns, [2] n_groups, [3] n_chunks,
+// [4] upper-triangular tile pairs, [5] K2 threads per block, [6] Z rows
+extern "C" int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]) {
+    if (!h || !out) return CVX_ERR_INVALID_ARG;
+    out[0] = h->ZC; out[1] = h->ns; out[2] = h->n_groups; out[3] = h->n_chunks; out[4] = h->ntp;
+    out[5] = h->T; out[6] = 6LL * h->V; out[7] = 0;
+    return CVX_OK;
+}

@@ -1,0 +1,759 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the camera-calibration LM iteration.
+// Included only by calib.hip.
+//
+// Functor restated per observation (one observation per lane):
+//   OpenCVReprojectionError + ApplyRadialDistortionCameraIntrinsics,
+//   /root/reference/modules/calib/src/calibration.cpp:231-311
+// with the analytic Jacobian that ceres::AutoDiffCostFunction<...,2,9,6,3> (calibration.cpp:391-398)
+// evaluates through Jets.  Internal column order of a residual row everywhere in this file:
+//   [0..5]  pose block   d/d(omega, t)
+//   [6..14] intrinsics   fx fy cx cy k1 k2 k3 p1 p2   (calibration.cpp:219-229)
+//   [15]    the residual itself
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cvxk {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RT_STRIDE = 40;    // per view: R[9] | dR/dw_j [3][9] | t[3] | pad
+constexpr int PT_ACC = 36;       // per point accumulators: Ucx[9][3] | Uxx[6] | gx[3]
+constexpr int AROW = 18;         // LDS stride (doubles) of one staged Jacobian row (16 + pad)
+constexpr int ZTILE = 48;        // Schur tile edge: 3 x 3 MFMA 16x16 blocks per wave
+
+// -----------------------------------------------------------------------------------------
+// K0: per-view rotation matrix and its derivative w.r.t. the global angle-axis vector
+// (both branches of ceres::AngleAxisRotatePoint, used at calibration.cpp:286)
+// -----------------------------------------------------------------------------------------
+__global__ void k_pose_prepare(const double *__restrict__ poses, double *__restrict__ rt, int V) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const double w0 = poses[6 * v], w1 = poses[6 * v + 1], w2 = poses[6 * v + 2];
+    double *o = rt + (size_t)v * RT_STRIDE;
+    const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+    double R[9], dR[3][9];
+    if (th2 > 2.220446049250313e-16) {
+        const double th = sqrt(th2), c = cos(th), s = sin(th), ti = 1.0 / th, omc = 1.0 - c;
+        const double a[3] = {w0 * ti, w1 * ti, w2 * ti};
+        // [a]x
+        const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+        for (int i = 0; i < 3; ++i)
+            for (int k = 0; k < 3; ++k)
+                R[i * 3 + k] = (i == k ? c : 0.0) + s * K[i * 3 + k] + omc * a[i] * a[k];
+        for (int j = 0; j < 3; ++j) {
+            // da/dw_j = (e_j - a a_j) / th
+            double da[3];
+            for (int i = 0; i < 3; ++i) da[i] = ((i == j ? 1.0 : 0.0) - a[i] * a[j]) * ti;
+            const double dK[9] = {0, -da[2], da[1], da[2], 0, -da[0], -da[1], da[0], 0};
+            for (int i = 0; i < 3; ++i)
+                for (int k = 0; k < 3; ++k)
+                    dR[j][i * 3 + k] = (i == k ? -s * a[j] : 0.0) + c * a[j] * K[i * 3 + k] + s * dK[i * 3 + k] +
+                                       s * a[j] * a[i] * a[k] + omc * (da[i] * a[k] + a[i] * da[k]);
+        }
+    } else {
+        const double Rs[9] = {1, -w2, w1, w2, 1, -w0, -w1, w0, 1};
+        for (int i = 0; i < 9; ++i) R[i] = Rs[i];
+        const double E0[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
+        const double E1[9] = {0, 0, 1, 0, 0, 0, -1, 0, 0};
+        const double E2[9] = {0, -1, 0, 1, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 9; ++i) { dR[0][i] = E0[i]; dR[1][i] = E1[i]; dR[2][i] = E2[i]; }
+    }
+    for (int i = 0; i < 9; ++i) o[i] = R[i];
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 9; ++i) o[9 + 9 * j + i] = dR[j][i];
+    o[36] = poses[6 * v + 3];
+    o[37] = poses[6 * v + 4];
+    o[38] = poses[6 * v + 5];
+    o[39] = 0.0;
+}
+
+struct Intr {
+    double fx, fy, cx, cy, k1, k2, k3, p1, p2;
+};
+
+__device__ __forceinline__ Intr load_intr(const double *__restrict__ p) {
+    Intr in;
+    in.fx = p[0]; in.fy = p[1]; in.cx = p[2]; in.cy = p[3];
+    in.k1 = p[4]; in.k2 = p[5]; in.k3 = p[6]; in.p1 = p[7]; in.p2 = p[8];
+    return in;
+}
+
+// residual only (calibration.cpp:266-311)
+__device__ __forceinline__ void reproj_residual(const Intr &in, const double *__restrict__ rt, double X0, double X1,
+                                                double X2, double ox, double oy, double &r0, double &r1) {
+    const double xc = rt[0] * X0 + rt[1] * X1 + rt[2] * X2 + rt[36];
+    const double yc = rt[3] * X0 + rt[4] * X1 + rt[5] * X2 + rt[37];
+    const double zc = rt[6] * X0 + rt[7] * X1 + rt[8] * X2 + rt[38];
+    const double iz = 1.0 / zc;
+    const double xn = xc * iz, yn = yc * iz;
+    const double r2 = xn * xn + yn * yn, r4 = r2 * r2, r6 = r4 * r2;
+    const double rc = 1.0 + in.k1 * r2 + in.k2 * r4 + in.k3 * r6;
+    const double xd = xn * rc + 2.0 * in.p1 * xn * yn + in.p2 * (r2 + 2.0 * xn * xn);
+    const double yd = yn * rc + 2.0 * in.p2 * xn * yn + in.p1 * (r2 + 2.0 * yn * yn);
+    r0 = in.fx * xd + in.cx - ox;
+    r1 = in.fy * yd + in.cy - oy;
+}
+
+// residual + Jacobian blocks, row-major Jp[2][6], Jc[2][9], Jx[2][3]
+__device__ __forceinline__ void reproj_jacobian(const Intr &in, const double *__restrict__ rt, double X0, double X1,
+                                                double X2, double ox, double oy, double &r0, double &r1,
+                                                double (&Jp)[12], double (&Jc)[18], double (&Jx)[6]) {
+    const double xc = rt[0] * X0 + rt[1] * X1 + rt[2] * X2 + rt[36];
+    const double yc = rt[3] * X0 + rt[4] * X1 + rt[5] * X2 + rt[37];
+    const double zc = rt[6] * X0 + rt[7] * X1 + rt[8] * X2 + rt[38];
+    const double iz = 1.0 / zc;
+    const double xn = xc * iz, yn = yc * iz;
+    const double r2 = xn * xn + yn * yn, r4 = r2 * r2, r6 = r4 * r2;
+    const double rc = 1.0 + in.k1 * r2 + in.k2 * r4 + in.k3 * r6;
+    const double xy2 = 2.0 * xn * yn;
+    const double tx = r2 + 2.0 * xn * xn, ty = r2 + 2.0 * yn * yn;
+    const double xd = xn * rc + in.p1 * xy2 + in.p2 * tx;
+    const double yd = yn * rc + in.p2 * xy2 + in.p1 * ty;
+    r0 = in.fx * xd + in.cx - ox;
+    r1 = in.fy * yd + in.cy - oy;
+    // intrinsics block
+    Jc[0] = xd;  Jc[9] = 0.0;
+    Jc[1] = 0.0; Jc[10] = yd;
+    Jc[2] = 1.0; Jc[11] = 0.0;
+    Jc[3] = 0.0; Jc[12] = 1.0;
+    const double fxx = in.fx * xn, fyy = in.fy * yn;
+    Jc[4] = fxx * r2; Jc[13] = fyy * r2;
+    Jc[5] = fxx * r4; Jc[14] = fyy * r4;
+    Jc[6] = fxx * r6; Jc[15] = fyy * r6;
+    Jc[7] = in.fx * xy2; Jc[16] = in.fy * ty;
+    Jc[8] = in.fx * tx;  Jc[17] = in.fy * xy2;
+    // d(xd,yd)/d(xn,yn)
+    const double rcp = in.k1 + 2.0 * in.k2 * r2 + 3.0 * in.k3 * r4;
+    const double dxx = rc + 2.0 * xn * xn * rcp + 2.0 * in.p1 * yn + 6.0 * in.p2 * xn;
+    const double dxy = xy2 * rcp + 2.0 * in.p1 * xn + 2.0 * in.p2 * yn;
+    const double dyy = rc + 2.0 * yn * yn * rcp + 2.0 * in.p2 * xn + 6.0 * in.p1 * yn;
+    const double a11 = in.fx * dxx, a12 = in.fx * dxy, a21 = in.fy * dxy, a22 = in.fy * dyy;
+    // D = d(u,v)/d(x_cam), 2x3
+    const double D00 = a11 * iz, D01 = a12 * iz, D02 = -(a11 * xn + a12 * yn) * iz;
+    const double D10 = a21 * iz, D11 = a22 * iz, D12 = -(a21 * xn + a22 * yn) * iz;
+    // G[i][j] = sum_k dR_j[i][k] X_k
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double *d = rt + 9 + 9 * j;
+        const double g0 = d[0] * X0 + d[1] * X1 + d[2] * X2;
+        const double g1 = d[3] * X0 + d[4] * X1 + d[5] * X2;
+        const double g2 = d[6] * X0 + d[7] * X1 + d[8] * X2;
+        Jp[j] = D00 * g0 + D01 * g1 + D02 * g2;
+        Jp[6 + j] = D10 * g0 + D11 * g1 + D12 * g2;
+    }
+    Jp[3] = D00; Jp[4] = D01; Jp[5] = D02;
+    Jp[9] = D10; Jp[10] = D11; Jp[11] = D12;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        Jx[j] = D00 * rt[j] + D01 * rt[3 + j] + D02 * rt[6 + j];
+        Jx[3 + j] = D10 * rt[j] + D11 * rt[3 + j] + D12 * rt[6 + j];
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// K1: evaluation mode -- residuals and Jacobian blocks materialised as component planes
+// out layout (doubles): r[2][N] | Jc[18][N] | Jp[12][N] | Jx[6][N]
+// -----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_eval(const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
+                                              const int *__restrict__ point_id, const double *__restrict__ obs_x,
+                                              const double *__restrict__ obs_y, const double *__restrict__ intr,
+                                              const double *__restrict__ points, const double *__restrict__ rt,
+                                              long long N, double *__restrict__ out) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    const int v = view_id[o], pid = point_id[o];
+    const Intr in = load_intr(intr + 9 * cam_of_view[v]);
+    const double *X = points + 3 * pid;
+    double r0, r1, Jp[12], Jc[18], Jx[6];
+    reproj_jacobian(in, rt + (size_t)v * RT_STRIDE, X[0], X[1], X[2], obs_x[o], obs_y[o], r0, r1, Jp, Jc, Jx);
+    double *p = out + o;
+    p[0] = r0; p[N] = r1;
+    p += 2 * N;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) p[(long long)i * N] = Jc[i];
+    p += 18 * N;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[(long long)i * N] = Jp[i];
+    p += 12 * N;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p[(long long)i * N] = Jx[i];
+}
+
+// -----------------------------------------------------------------------------------------
+// K4: cost only.  One partial (sum r^2) per block, summed later in fixed order.
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double *sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    return t;
+}
+
+__global__ void __launch_bounds__(256) k_cost(const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
+                                              const int *__restrict__ point_id, const double *__restrict__ obs_x,
+                                              const double *__restrict__ obs_y, const double *__restrict__ intr,
+                                              const double *__restrict__ points, const double *__restrict__ rt,
+                                              long long N, double *__restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < N; o += stride) {
+        const int v = view_id[o], pid = point_id[o];
+        const Intr in = load_intr(intr + 9 * cam_of_view[v]);
+        const double *X = points + 3 * pid;
+        double r0, r1;
+        reproj_residual(in, rt + (size_t)v * RT_STRIDE, X[0], X[1], X[2], obs_x[o], obs_y[o], r0, r1);
+        acc += r0 * r0 + r1 * r1;
+    }
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// -----------------------------------------------------------------------------------------
+// 6x6 SPD block: Cholesky factor and its inverse, packed lower triangle idx(i,j)=i(i+1)/2+j
+// -----------------------------------------------------------------------------------------
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+
+__device__ __forceinline__ bool chol6_inverse(const double (&A)[21], double (&M)[21]) {
+    double L[21], invd[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = A[TRI(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[TRI(j, k)] * L[TRI(j, k)];
+        ok = ok && (s > 0.0) && (s < 1.7e308);
+        const double ri = ok ? rsqrt(s) : 0.0;
+        invd[j] = ri;
+        L[TRI(j, j)] = s * ri;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[TRI(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[TRI(i, k)] * L[TRI(j, k)];
+            L[TRI(i, j)] = t * ri;
+        }
+    }
+    // M = L^-1 (lower)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        M[TRI(j, j)] = invd[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) t += L[TRI(i, k)] * M[TRI(k, j)];
+            M[TRI(i, j)] = -t * invd[i];
+        }
+    }
+    return ok;
+}
+
+// -----------------------------------------------------------------------------------------
+// K2: fused residual + Jacobian + normal-equation blocks, one workgroup per group of views
+// (all of one camera), one observation per lane, views in sequence.
+//
+// Per view:   G = A^T A for A = [Jp | Jc | r] (rows: 2 per observation) on fp64 MFMA,
+//             giving V_v (6x6), W_vc (6x9), g_v, and this view's share of U_cc, g_c, cost;
+//             D_v from diag(V_v); Linv = chol(V_v + D_v)^-1;
+//             Z_v = Linv [W_vx | W_vc | g_v] written to HBM (row-major, ZC columns);
+// per point:  U_cx, U_xx, g_x accumulated in LDS across the group's views.
+// MODE 0: as above.  MODE 1 (initial linearisation): no damping/factor/Z; writes the Jacobi
+//         scales s_j^2 = 1/(1+sqrt(d_j))^2 of the pose parameters when s2pose_out != null.
+// -----------------------------------------------------------------------------------------
+struct K2Args {
+    const int *view_off, *cam_of_view, *point_id;
+    const double *obs_x, *obs_y, *intr, *points, *rt, *s2pose;
+    const int *grp_v0;
+    int P, ZC, camcol0, ycol, cam_free, pts_free;
+    double inv_radius, mu, min_diag, max_diag;
+    double *Z, *Linv, *Dv, *gv, *s2pose_out, *slab_pt, *slab_cam, *grp_scal;
+};
+
+template <int T, int MODE>
+__global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
+    extern __shared__ double lds[];
+    constexpr int W = T / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *accpt = lds;                                // [P * PT_ACC]
+    double *arows = accpt + a.P * PT_ACC;               // [W][64 * AROW]
+    double *tiles = arows + W * 64 * AROW;              // [W][256]
+    double *gsum = tiles + W * 256;                     // [256]
+    for (int e = tid; e < a.P * PT_ACC; e += T) accpt[e] = 0.0;
+
+    const int g = blockIdx.x;
+    const int v0 = a.grp_v0[g], v1 = a.grp_v0[g + 1];
+    const int cam = a.cam_of_view[v0];
+    const Intr in = load_intr(a.intr + 9 * cam);
+    f64x4 acc_tot = {0.0, 0.0, 0.0, 0.0};
+    double gmax = 0.0, dmax = 0.0, nbad = 0.0;
+    double *myrows = arows + wave * 64 * AROW;
+    __syncthreads();
+
+    for (int v = v0; v < v1; ++v) {
+        const int base = a.view_off[v];
+        const int n = a.view_off[v + 1] - base;
+        const double *rt = a.rt + (size_t)v * RT_STRIDE;
+        const bool active = tid < n;
+        double r[2] = {0.0, 0.0}, Jp[12], Jc[18], Jx[6];
+        int pid = 0;
+        if (active) {
+            pid = a.point_id[base + tid];
+            const double *X = a.points + 3 * pid;
+            reproj_jacobian(in, rt, X[0], X[1], X[2], a.obs_x[base + tid], a.obs_y[base + tid], r[0], r[1], Jp, Jc, Jx);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Jp[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) Jc[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Jx[i] = 0.0;
+        }
+        // ---- Gram of the staged rows on the matrix cores ----
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double *row = myrows + lane * AROW;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) row[i] = Jp[6 * h + i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) row[6 + i] = Jc[9 * h + i];
+            row[15] = r[h];
+            __builtin_amdgcn_wave_barrier();
+            const double *src = myrows + (lane >> 4) * AROW + (lane & 15);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const double val = src[4 * s * AROW];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(val, val, acc, 0, 0, 0);
+            }
+        }
+        // acc[i] = G[(lane>>4) + 4 i][lane & 15] for this wave's observations
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tiles[wave * 256 + ((lane >> 4) + 4 * i) * 16 + (lane & 15)] = acc[i];
+        acc_tot += acc;
+        __syncthreads();
+        for (int e = tid; e < 256; e += T) {
+            double s = tiles[e];
+#pragma unroll
+            for (int w = 1; w < W; ++w) s += tiles[w * 256 + e];
+            gsum[e] = s;
+        }
+        __syncthreads();
+
+        // ---- pose block: damping, factor, inverse (every lane redundantly, operands broadcast) ----
+        double A[21], gvv[6], Dd[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) A[TRI(i, j)] = gsum[i * 16 + j];
+            gvv[i] = gsum[i * 16 + 15];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double d = A[TRI(i, i)];
+            dmax = fmax(dmax, d);
+            gmax = fmax(gmax, fabs(gvv[i]));
+            if (MODE == 0) {
+                const double s2 = a.s2pose[6 * v + i];
+                double c = s2 * d;
+                c = fmin(fmax(c, a.min_diag), a.max_diag);
+                Dd[i] = c * a.inv_radius / s2 + a.mu;
+                A[TRI(i, i)] = d + Dd[i];
+            } else {
+                Dd[i] = d;
+            }
+        }
+        if (MODE == 1) {
+            if (a.s2pose_out && tid < 6) {
+                const double s = 1.0 / (1.0 + sqrt(gsum[tid * 16 + tid]));
+                a.s2pose_out[6 * v + tid] = s * s;
+            }
+        }
+        if (MODE == 0) {
+            double M[21];
+            const bool ok = chol6_inverse(A, M);
+            if (!ok) nbad = 1.0;
+            double *Zv = a.Z + (size_t)6 * v * a.ZC;
+            // point columns: Z[a][3 pid + b] = sum_{k<=a} M[a][k] (Jp^T Jx)[k][b]
+            if (active && a.pts_free) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    double w[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) w[k] = Jp[k] * Jx[b] + Jp[6 + k] * Jx[3 + b];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        double z = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= i; ++k) z += M[TRI(i, k)] * w[k];
+                        Zv[(size_t)i * a.ZC + 3 * pid + b] = z;
+                    }
+                }
+            }
+            // camera columns (lanes 0..8), reduced-gradient column (lane 9), per-view records (lane 10)
+            if (tid < 10) {
+                const bool isy = (tid == 9);
+                if (isy || a.cam_free) {
+                    double w[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) w[k] = isy ? gvv[k] : gsum[k * 16 + 6 + tid];
+                    const int col = isy ? a.ycol : a.camcol0 + tid;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        double z = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= i; ++k) z += M[TRI(i, k)] * w[k];
+                        Zv[(size_t)i * a.ZC + col] = z;
+                    }
+                }
+            } else if (tid == 10) {
+#pragma unroll
+                for (int i = 0; i < 21; ++i) a.Linv[(size_t)21 * v + i] = M[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    a.Dv[6 * v + i] = Dd[i];
+                    a.gv[6 * v + i] = gvv[i];
+                }
+            }
+        }
+        // ---- per-point accumulators (unique point ids inside a view: plain read-modify-write) ----
+        if (active && a.pts_free) {
+            double *pa = accpt + pid * PT_ACC;
+            if (a.cam_free) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) pa[c * 3 + b] += Jc[c] * Jx[b] + Jc[9 + c] * Jx[3 + b];
+            }
+            pa[27] += Jx[0] * Jx[0] + Jx[3] * Jx[3];
+            pa[28] += Jx[0] * Jx[1] + Jx[3] * Jx[4];
+            pa[29] += Jx[0] * Jx[2] + Jx[3] * Jx[5];
+            pa[30] += Jx[1] * Jx[1] + Jx[4] * Jx[4];
+            pa[31] += Jx[1] * Jx[2] + Jx[4] * Jx[5];
+            pa[32] += Jx[2] * Jx[2] + Jx[5] * Jx[5];
+            pa[33] += Jx[0] * r[0] + Jx[3] * r[1];
+            pa[34] += Jx[1] * r[0] + Jx[4] * r[1];
+            pa[35] += Jx[2] * r[0] + Jx[5] * r[1];
+        }
+        __syncthreads();
+    }
+    // ---- flush the group's accumulators ----
+    double *sp = a.slab_pt + (size_t)g * a.P * PT_ACC;
+    if (a.pts_free)
+        for (int e = tid; e < a.P * PT_ACC; e += T) sp[e] = accpt[e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tiles[wave * 256 + ((lane >> 4) + 4 * i) * 16 + (lane & 15)] = acc_tot[i];
+    __syncthreads();
+    for (int e = tid; e < 256; e += T) {
+        double s = tiles[e];
+#pragma unroll
+        for (int w = 1; w < W; ++w) s += tiles[w * 256 + e];
+        a.slab_cam[(size_t)g * 256 + e] = s;
+    }
+    if (tid == 0) {
+        a.grp_scal[4 * g + 0] = gmax;
+        a.grp_scal[4 * g + 1] = dmax;
+        a.grp_scal[4 * g + 2] = nbad;
+        a.grp_scal[4 * g + 3] = 0.0;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// K3: Schur contraction  Z^T Z  on fp64 MFMA (v_mfma_f64_16x16x4_f64).
+// One wave per (48x48 upper-triangular tile, chunk of rows); partial tiles go to a slab and
+// are summed in fixed order by k_assemble.  Blocks are dealt round-robin over the 8 XCDs, so
+// the remap below keeps all tiles of one chunk on one XCD (one L2 holds that chunk's rows).
+// -----------------------------------------------------------------------------------------
+struct K3Args {
+    const double *Z;
+    const int *chk_row0;   // [n_chunks + 1] first row of each chunk
+    double *slab;          // [n_chunks][ntp][48*48]
+    int ZC, n_chunks, nt, ntp, nbc;
+};
+
+__global__ void __launch_bounds__(256) k_schur_syrk(K3Args a) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int chunk = (slot / a.nbc) * 8 + xcd;
+    if (chunk >= a.n_chunks) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tp = (slot % a.nbc) * 4 + wave;
+    if (tp >= a.ntp) return;
+    int ti = 0, rem = tp;
+    while (rem >= a.nt - ti) { rem -= a.nt - ti; ++ti; }
+    const int tj = ti + rem;
+    const int r0 = a.chk_row0[chunk], r1 = a.chk_row0[chunk + 1];
+    const int kq = lane >> 4, cq = lane & 15;
+    const double *pa = a.Z + ti * ZTILE + cq;
+    const double *pb = a.Z + tj * ZTILE + cq;
+    const bool diag = (ti == tj);
+    f64x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    double ca[3], cb[3];
+    {
+        const int row = r0 + kq;
+        const bool ok = row < r1;
+        const size_t off = (size_t)(ok ? row : r0) * a.ZC;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ca[i] = ok ? pa[off + 16 * i] : 0.0;
+            cb[i] = diag ? ca[i] : (ok ? pb[off + 16 * i] : 0.0);
+        }
+    }
+    for (int k = r0; k < r1; k += 4) {
+        double na[3], nb[3];
+        {
+            const int row = k + 4 + kq;
+            const bool ok = row < r1;
+            const size_t off = (size_t)(ok ? row : r0) * a.ZC;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                na[i] = ok ? pa[off + 16 * i] : 0.0;
+                nb[i] = diag ? na[i] : (ok ? pb[off + 16 * i] : 0.0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+    }
+    double *out = a.slab + ((size_t)chunk * a.ntp + tp) * (ZTILE * ZTILE);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[(16 * i + kq + 4 * q) * ZTILE + 16 * j + cq] = acc[i][j][q];
+}
+
+// -----------------------------------------------------------------------------------------
+// U-reduce: sum the per-group slabs in fixed order.
+//   Ucx[C][P][27], Uxx[P][9] (6 Hessian + 3 gradient), Gcam[C][256], scal[4]
+// -----------------------------------------------------------------------------------------
+struct URArgs {
+    const double *slab_pt, *slab_cam, *grp_scal;
+    const int *glist, *glist_off;   // groups of each camera: glist[glist_off[c] .. glist_off[c+1])
+    int n_groups, C, P, cam_free, pts_free;
+    double *Ucx, *Uxx, *Gcam;
+    double *out_sum, *out_bad, *out_gmax, *out_dmax;   // sum r^2, bad pose blocks, max |g_pose|, max diag V
+};
+
+__global__ void __launch_bounds__(256) k_ureduce(URArgs a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_ucx = (a.cam_free && a.pts_free) ? (long long)a.C * a.P * 27 : 0;
+    const long long n_uxx = a.pts_free ? (long long)a.P * 9 : 0;
+    const long long n_gcam = (long long)a.C * 256;
+    if (t < n_ucx) {
+        const int c = (int)(t / (a.P * 27)), rem = (int)(t % (a.P * 27));
+        const int p = rem / 27, k = rem % 27;
+        double s = 0.0;
+        for (int q = a.glist_off[c]; q < a.glist_off[c + 1]; ++q)
+            s += a.slab_pt[((size_t)a.glist[q] * a.P + p) * PT_ACC + k];
+        a.Ucx[t] = s;
+        return;
+    }
+    long long u = t - n_ucx;
+    if (u < n_uxx) {
+        const int p = (int)(u / 9), k = (int)(u % 9);
+        double s = 0.0;
+        for (int q = 0; q < a.n_groups; ++q) s += a.slab_pt[((size_t)q * a.P + p) * PT_ACC + 27 + k];
+        a.Uxx[u] = s;
+        return;
+    }
+    u -= n_uxx;
+    if (u < n_gcam) {
+        const int c = (int)(u / 256), e = (int)(u % 256);
+        double s = 0.0;
+        for (int q = a.glist_off[c]; q < a.glist_off[c + 1]; ++q) s += a.slab_cam[(size_t)a.glist[q] * 256 + e];
+        a.Gcam[u] = s;
+        return;
+    }
+    u -= n_gcam;
+    if (u == 0) {
+        double s = 0.0, gm = 0.0, dm = 0.0, nb = 0.0;
+        for (int q = 0; q < a.n_groups; ++q) {
+            s += a.slab_cam[(size_t)q * 256 + 255];
+            gm = fmax(gm, a.grp_scal[4 * q]);
+            dm = fmax(dm, a.grp_scal[4 * q + 1]);
+            nb += a.grp_scal[4 * q + 2];
+        }
+        *a.out_sum = s; *a.out_bad = nb; *a.out_gmax = gm; *a.out_dmax = dm;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// Assemble the exchange buffer E (one thread per entry):
+//   E = [ S = U - Z^T Z (ns*ns) | gred (ns) | gs (ns) | diagU (ns) | scalars... ]
+// shared-parameter order (API): free intrinsics of camera 0, 1, ..., then points xyz.
+// -----------------------------------------------------------------------------------------
+struct AsmArgs {
+    const double *slab, *Ucx, *Uxx, *Gcam;
+    const int *chk_cam;
+    int ns, C, P, ncf, fix_k3, pts_free, ZC, camcol0, ycol, nt, ntp, n_chunks;
+    double *E;
+};
+
+struct SharedIdx {
+    int is_cam, c, kk, p, b, zcol;
+};
+
+__device__ __forceinline__ SharedIdx shared_index(const AsmArgs &a, int i) {
+    SharedIdx s;
+    const int ncam = a.C * a.ncf;
+    if (i < ncam) {
+        s.is_cam = 1; s.c = i / a.ncf;
+        const int k = i % a.ncf;
+        s.kk = (a.fix_k3 && k >= 6) ? k + 1 : k;
+        s.p = 0; s.b = 0; s.zcol = a.camcol0 + s.kk;
+    } else {
+        const int q = i - ncam;
+        s.is_cam = 0; s.c = -1; s.kk = 0; s.p = q / 3; s.b = q % 3; s.zcol = q;
+    }
+    return s;
+}
+
+__device__ __forceinline__ double tile_value(const AsmArgs &a, int ch, int zi, int zj) {
+    int ti = zi / ZTILE, tj = zj / ZTILE;
+    if (ti > tj) { int t = ti; ti = tj; tj = t; t = zi; zi = zj; zj = t; }
+    const int tp = ti * a.nt - ti * (ti - 1) / 2 + (tj - ti);
+    return a.slab[((size_t)ch * a.ntp + tp) * (ZTILE * ZTILE) + (zi % ZTILE) * ZTILE + (zj % ZTILE)];
+}
+
+__global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nn = (long long)a.ns * a.ns;
+    if (t >= nn + a.ns) return;
+    const int sym6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    if (t < nn) {
+        const int i = (int)(t / a.ns), j = (int)(t % a.ns);
+        const SharedIdx si = shared_index(a, i), sj = shared_index(a, j);
+        double u = 0.0;
+        if (si.is_cam && sj.is_cam) {
+            if (si.c == sj.c) u = a.Gcam[(size_t)si.c * 256 + (6 + si.kk) * 16 + 6 + sj.kk];
+        } else if (si.is_cam) {
+            u = a.Ucx[((size_t)si.c * a.P + sj.p) * 27 + si.kk * 3 + sj.b];
+        } else if (sj.is_cam) {
+            u = a.Ucx[((size_t)sj.c * a.P + si.p) * 27 + sj.kk * 3 + si.b];
+        } else if (si.p == sj.p) {
+            u = a.Uxx[si.p * 9 + sym6[si.b * 3 + sj.b]];
+        }
+        double z = 0.0;
+        const bool cross_cam = si.is_cam && sj.is_cam && si.c != sj.c;
+        if (!cross_cam)
+            for (int ch = 0; ch < a.n_chunks; ++ch) {
+                const int cc = a.chk_cam[ch];
+                if (si.is_cam && cc != si.c) continue;
+                if (sj.is_cam && cc != sj.c) continue;
+                z += tile_value(a, ch, si.zcol, sj.zcol);
+            }
+        a.E[t] = u - z;
+    } else {
+        const int i = (int)(t - nn);
+        const SharedIdx si = shared_index(a, i);
+        double g, d;
+        if (si.is_cam) {
+            g = a.Gcam[(size_t)si.c * 256 + (6 + si.kk) * 16 + 15];
+            d = a.Gcam[(size_t)si.c * 256 + (6 + si.kk) * 16 + 6 + si.kk];
+        } else {
+            g = a.Uxx[si.p * 9 + 6 + si.b];
+            d = a.Uxx[si.p * 9 + sym6[si.b * 4]];
+        }
+        double z = 0.0;
+        for (int ch = 0; ch < a.n_chunks; ++ch) {
+            if (si.is_cam && a.chk_cam[ch] != si.c) continue;
+            z += tile_value(a, ch, si.zcol, a.ycol);
+        }
+        a.E[nn + i] = g - z;
+        a.E[nn + a.ns + i] = g;
+        a.E[nn + 2 * a.ns + i] = d;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// K6: back-substitution, one wave per view:
+//   t = Z_v * ds_emb[cam]  (ds_emb has 1 in the y column)   ->  dp = -Linv^T t
+//   candidate pose = pose + dp;  per-view sums for the step evaluation
+// out_view[v] = { dp^T (D dp - g), |dp|^2, |pose|^2 }
+// -----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z, const double *__restrict__ Linv,
+                                                   const double *__restrict__ Dv, const double *__restrict__ gv,
+                                                   const double *__restrict__ ds_emb,
+                                                   const int *__restrict__ cam_of_view,
+                                                   const double *__restrict__ poses, double *__restrict__ poses_cand,
+                                                   double *__restrict__ dposes, double *__restrict__ out_view, int V,
+                                                   int ZC) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const double *ds = ds_emb + (size_t)cam_of_view[v] * ZC;
+    const double *Zv = Z + (size_t)6 * v * ZC;
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = lane; c < ZC; c += 64) {
+        const double d = ds[c];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i] += Zv[(size_t)i * ZC + c] * d;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t[i] += __shfl_xor(t[i], off, 64);
+    if (lane == 0) {
+        const double *M = Linv + (size_t)21 * v;
+        double m = 0.0, s2 = 0.0, x2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double dp = 0.0;
+#pragma unroll
+            for (int k = i; k < 6; ++k) dp += M[TRI(k, i)] * t[k];
+            dp = -dp;
+            const double p = poses[6 * v + i];
+            poses_cand[6 * v + i] = p + dp;
+            if (dposes) dposes[6 * v + i] = dp;
+            m += dp * (Dv[6 * v + i] * dp - gv[6 * v + i]);
+            s2 += dp * dp;
+            x2 += p * p;
+        }
+        out_view[3 * v] = m;
+        out_view[3 * v + 1] = s2;
+        out_view[3 * v + 2] = x2;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// final scalar reduction (single block, fixed order):
+//   E2 = { sum cost partials, sum out_view[.][0], sum out_view[.][1], sum out_view[.][2] }
+// -----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_final_scalars(const double *__restrict__ cost_partial, int n_partial,
+                                                       const double *__restrict__ out_view, int V,
+                                                       double *__restrict__ E2) {
+    __shared__ double sh[4][256];
+    double s[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n_partial; i += 256) s[0] += cost_partial[i];
+    for (int i = threadIdx.x; i < V; i += 256) {
+        s[1] += out_view[3 * i];
+        s[2] += out_view[3 * i + 1];
+        s[3] += out_view[3 * i + 2];
+    }
+    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off)
+            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) E2[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+}  // namespace cvxk

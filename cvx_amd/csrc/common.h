@@ -1,0 +1,32 @@
+// Shared host helpers for the HIP translation units of libcvx_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/cvx_amd.h"
+
+namespace cvx {
+
+// thread-local last error text (cvx_last_error)
+void set_last_error(const std::string &s);
+
+inline int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    set_last_error(buf);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? CVX_ERR_NO_DEVICE : CVX_ERR_HIP;
+}
+
+#define CVX_HIP(call)                                                         \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return cvx::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// blocked Cholesky solve of an SPD system on the host: A (n x n row-major, lower triangle
+// read, destroyed), b in/out.  Returns false when A is not numerically positive definite.
+bool host_cholesky_solve(int n, double *A, double *b);
+
+}  // namespace cvx

@@ -1,0 +1,257 @@
+/*
+ * cvx_amd.h -- C ABI of the MI355X-native cvx_calibration NLLS inner loop.
+ *
+ * One shared library, libcvx_amd.so, built from cvx_amd/csrc (HIP for gfx950 +
+ * host C++).  Plain pointers and sizes only; no C++ or torch types cross this
+ * boundary.  The reference (angeltop/cvx) has no FFI layer of its own for this
+ * path: the functions below are what a header-only adaptor behind
+ *   double CameraCalibration::refine(const Data&, PinholeCamera&, std::vector<Eigen::Matrix4d>&, bool)
+ *       modules/calib/include/cvx/calib/calibration.hpp:33, impl modules/calib/src/calibration.cpp:354-464
+ *   bool HandEyeCalibration::solveFixed / solveMoving(...)
+ *       modules/calib/include/cvx/calib/handeye.hpp:25-30, impl modules/calib/src/handeye.cpp:665-764
+ * binds (see INTEGRATION.md and cvx_amd/include/cvx_amd/calib_adaptor.hpp).
+ *
+ * Every function returns a cvx_status (0 = ok) unless stated.  All host
+ * pointers; device memory is owned by the handles.  Handles are
+ * thread-compatible (one thread at a time per handle), no global state.
+ * The library never falls back to a CPU path: without a usable HIP device
+ * every compute entry point returns CVX_ERR_NO_DEVICE.
+ */
+#ifndef CVX_AMD_H
+#define CVX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    CVX_OK = 0,
+    CVX_ERR_INVALID_ARG = 1,
+    CVX_ERR_NO_DEVICE = 2,
+    CVX_ERR_HIP = 3,
+    CVX_ERR_UNSUPPORTED = 4,       /* size beyond a documented kernel limit */
+    CVX_ERR_DUPLICATE_MARKER = 5,  /* a view lists the same board point twice */
+    CVX_ERR_EXCHANGE = 6,          /* the all-reduce hook failed */
+    CVX_ERR_NUMERIC = 7            /* non-finite cost at the initial point */
+} cvx_status;
+
+const char *cvx_status_string(int status);
+/* last HIP / RCCL error text seen on this thread ("" if none) */
+const char *cvx_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int cvx_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Levenberg-Marquardt control (host side, shared by both problems)          */
+/* ------------------------------------------------------------------------ */
+/* strategy 0: the trust-region LM ceres::Solve runs with the options set at
+ *   calibration.cpp:420-428 / handeye.cpp:310-319 (Ceres defaults elsewhere);
+ * strategy 1: levmar's Nielsen damping, lm_core.c:257-409 (what LMSolver,
+ *   modules/util/include/cvx/util/math/solvers/lm.hpp:39-110, drives). */
+typedef struct {
+    int strategy;
+    int max_iterations;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_radius, max_radius, min_radius, min_relative_decrease;
+    double min_lm_diagonal, max_lm_diagonal;
+    int jacobi_scaling;
+    int nonmonotonic;
+    int max_consecutive_nonmonotonic_steps;
+    double tau, eps1, eps2, eps3;
+} cvx_lm_options;
+
+#define CVX_TRACE_MAX 1024
+typedef struct {
+    int iterations, num_successful, num_linear_solves;
+    int termination;   /* strategy 0: 1 gradient tol, 2 parameter tol, 3 function tol, 4 max iterations,
+                                      5 radius below minimum, 6 repeated invalid steps;
+                          strategy 1: levmar info[6] codes 1..7 */
+    double initial_cost, final_cost;   /* 1/2 sum r^2 */
+    int trace_len;
+    double trace_cost[CVX_TRACE_MAX];      /* candidate cost of every linear solve (NaN: solve failed) */
+    double trace_accepted[CVX_TRACE_MAX];
+    double trace_damping[CVX_TRACE_MAX];   /* radius (strategy 0) or mu (strategy 1) */
+    double trace_gradient[CVX_TRACE_MAX];  /* max-norm gradient at the linearisation point */
+    double seconds_total;                  /* wall time inside the solve */
+} cvx_lm_summary;
+
+void cvx_lm_options_refine(cvx_lm_options *o);   /* calibration.cpp:420-428 */
+void cvx_lm_options_handeye(cvx_lm_options *o);  /* handeye.cpp:310-319 */
+void cvx_lm_options_levmar(cvx_lm_options *o);   /* lm.hpp:43-50,61 */
+
+/* ------------------------------------------------------------------------ */
+/* Exchange step for view-sharded multi-GPU runs                             */
+/* ------------------------------------------------------------------------ */
+/* Sums `count` doubles in place over all ranks.  `on_device` tells whether buf
+ * is device memory (then `stream` is the hipStream_t the data is ordered on)
+ * or host memory.  Return 0 on success. */
+typedef int (*cvx_allreduce_fn)(void *ctx, double *buf, size_t count, int on_device, void *stream);
+
+/* built-in RCCL implementation of the hook (one communicator per process/GPU) */
+#define CVX_RCCL_ID_BYTES 128
+int cvx_rccl_unique_id(char id[CVX_RCCL_ID_BYTES]);
+int cvx_rccl_create(int rank, int nranks, const char id[CVX_RCCL_ID_BYTES], int device, void **comm);
+int cvx_rccl_allreduce(void *comm, double *buf, size_t count, int on_device, void *stream);
+void cvx_rccl_destroy(void *comm);
+
+/* contiguous view ranges balanced by observation count: first_view[nranks+1] */
+int cvx_partition_views(int n_views, const int *view_off, int nranks, int *first_view);
+
+/* ------------------------------------------------------------------------ */
+/* Camera calibration bundle adjustment (CameraCalibration::refine)          */
+/* ------------------------------------------------------------------------ */
+typedef struct cvx_calib cvx_calib;
+
+typedef struct {
+    int n_cameras;            /* the reference has exactly one (calibration.hpp:31-33) */
+    int n_views;              /* (camera, view) pose blocks held by THIS rank */
+    int n_points;             /* board points, Data::coords_ (calibration.hpp:20) */
+    int64_t n_obs;            /* sum of markers_[i].size() */
+    const int *cam_of_view;   /* [n_views] */
+    const int *view_off;      /* [n_views + 1] CSR offsets into the observation arrays */
+    const int *point_id;      /* [n_obs]  Marker::id_  (pattern.hpp:23) */
+    const double *obs_x;      /* [n_obs]  Marker::pt_.x promoted to double (calibration.cpp:393) */
+    const double *obs_y;
+    int fix_k3;               /* 1 in the reference (calibration.cpp:410-415) */
+    int fix_intrinsics;       /* refine(..., intrinsics = false), calibration.cpp:407-408 */
+    int fix_points;           /* 0 in the reference (board points are free blocks, calibration.cpp:397) */
+    int device;               /* HIP device ordinal */
+    void *stream;             /* hipStream_t to run on, or NULL: the handle creates its own */
+} cvx_calib_desc;
+
+/* limits of this build (CVX_ERR_UNSUPPORTED beyond them) */
+#define CVX_MAX_MARKERS_PER_VIEW 1024
+#define CVX_MAX_POINTS 448
+#define CVX_MAX_CAMERAS 64
+
+int cvx_calib_create(const cvx_calib_desc *desc, cvx_calib **out);
+void cvx_calib_destroy(cvx_calib *h);
+
+/* parameter blocks in the reference's layouts: intrinsics[n_cameras][9] in the order
+ * fx,fy,cx,cy,k1,k2,k3,p1,p2 (calibration.cpp:219-229); poses[n_views][6] = angle-axis, t
+ * (calibration.cpp:318-332); points[n_points][3] */
+int cvx_calib_set_params(cvx_calib *h, const double *intrinsics, const double *poses, const double *points);
+int cvx_calib_get_params(cvx_calib *h, double *intrinsics, double *poses, double *points);
+
+/* size of the reduced (Schur) system: free intrinsics of every camera, then free points */
+int cvx_calib_num_shared(const cvx_calib *h);
+
+/* 1/2 sum r^2 over this rank's observations (Problem::Evaluate, calibration.cpp:438-442) */
+int cvx_calib_cost(cvx_calib *h, double *cost);
+
+/* residuals and Jacobian blocks exactly as the AutoDiffCostFunction<..,2,9,6,3> of
+ * calibration.cpp:391-398 yields them, per observation, row-major:
+ *   r[n_obs][2], Jc[n_obs][2][9], Jp[n_obs][2][6], Jx[n_obs][2][3]; any may be NULL. */
+int cvx_calib_evaluate(cvx_calib *h, double *cost, double *r, double *Jc, double *Jp, double *Jx);
+
+/* The same evaluation left in HBM as component planes (SoA): r[2][n_obs], Jc[18][n_obs],
+ * Jp[12][n_obs], Jx[6][n_obs] written into the handle's own device buffer (allocated on
+ * first use, 36 doubles per observation + residuals).  Asynchronous on the handle's stream;
+ * *device_buffer receives the device address (layout: r | Jc | Jp | Jx planes). */
+int cvx_calib_evaluate_device(cvx_calib *h, void **device_buffer);
+
+/* damping of one linear solve: D_j = clamp(s_j^2 d_j, min_diag, max_diag) * inv_radius / s_j^2 + mu
+ * with d_j = (J^T J)_jj and s_j the Jacobi scale (1 unless cvx_calib_init_scaling ran) */
+typedef struct {
+    double inv_radius, mu, min_diag, max_diag;
+} cvx_damping;
+
+/* fixes s_j = 1 / (1 + sqrt(d_j)) from the Jacobian at the current parameters (Ceres
+ * jacobi_scaling); enable = 0 resets s_j = 1 */
+int cvx_calib_init_scaling(cvx_calib *h, int enable);
+
+/* One damped linear solve at the current parameters, without changing them.
+ * Outputs (any may be NULL): S[ns*ns] damped reduced matrix, gred[ns] reduced gradient,
+ * delta_shared[ns], delta_poses[n_views*6], cost (at the current parameters),
+ * cand_cost (at parameters + delta), model_change = 1/2 delta^T (D delta - g). */
+int cvx_calib_linear_step(cvx_calib *h, const cvx_damping *d, double *S, double *gred,
+                          double *delta_shared, double *delta_poses, double *cost,
+                          double *cand_cost, double *model_change);
+
+/* multi-GPU: this rank holds views [its shard]; shared blocks are replicated */
+int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks,
+                           int device_buffers);
+
+/* the whole LM solve (ceres::Solve at calibration.cpp:433); parameters are updated in place */
+int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *summary);
+
+/* value CameraCalibration::refine returns: sqrt(total_cost / (2 n_obs)), calibration.cpp:463 */
+double cvx_calib_refine_return(double total_cost, int64_t n_obs_total);
+
+/* per-phase device time (ms) of the last cvx_calib_solve / cvx_calib_linear_step, measured
+ * with hipEvents on the handle's stream: [0] normal-equation kernel, [1] Schur contraction,
+ * [2] assemble, [3] back-substitution, [4] candidate cost, [5] launches counted */
+int cvx_calib_phase_times(cvx_calib *h, double ms[8]);
+
+/* ------------------------------------------------------------------------ */
+/* Hand-eye AX = XB refinement (HandEyeCalibration::solveNonLinear)          */
+/* ------------------------------------------------------------------------ */
+typedef struct cvx_handeye cvx_handeye;
+
+/* motion pairs as unit quaternions (w,x,y,z) + translations, handeye.cpp:286-291 */
+int cvx_handeye_create(int n_pairs, const double *qa, const double *ta, const double *qb,
+                       const double *tb, int device, void *stream, cvx_handeye **out);
+void cvx_handeye_destroy(cvx_handeye *h);
+/* p = {q.w,q.x,q.y,q.z,tx,ty,tz} (handeye.cpp:279-280) */
+int cvx_handeye_cost(cvx_handeye *h, const double p[7], double *cost);
+/* 6-dof normal equations through QuaternionParameterization: H[36], g[6], cost */
+int cvx_handeye_normal_eq(cvx_handeye *h, const double p[7], double H[36], double g[6], double *cost);
+/* residuals r[n][12] and global Jacobians Jq[n][12][4], Jt[n][12][3] (any may be NULL) */
+int cvx_handeye_evaluate(cvx_handeye *h, const double p[7], double *r, double *Jq, double *Jt);
+int cvx_handeye_set_exchange(cvx_handeye *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks,
+                             int device_buffers);
+int cvx_handeye_solve(cvx_handeye *h, double p[7], const cvx_lm_options *opt, cvx_lm_summary *summary);
+
+/* ------------------------------------------------------------------------ */
+/* Host-side conversions the adaptor needs (no device work)                  */
+/* ------------------------------------------------------------------------ */
+/* ceres::RotationMatrixToAngleAxis / AngleAxisToRotationMatrix on COLUMN-major 3x3
+ * (calibration.cpp:328,344) */
+void cvx_rotation_to_angle_axis(const double R_colmajor[9], double w[3]);
+void cvx_angle_axis_to_rotation(const double w[3], double R_colmajor[9]);
+/* Eigen::Quaterniond(R) on a column-major 3x3; q = (w,x,y,z) */
+void cvx_rotation_to_quaternion(const double R_colmajor[9], double q[4]);
+/* 4x4 column-major rigid transforms -> (q, t) of handeye.cpp:286-291 */
+void cvx_affine_to_quat_trans(const double T_colmajor[16], double q[4], double t[3]);
+/* X = Translation(t) * q.toRotationMatrix(), handeye.cpp:326-330 */
+void cvx_quat_trans_to_affine(const double p[7], double T_colmajor[16]);
+
+/* motion-pair construction of solveFixed (handeye.cpp:681-693) and solveMoving
+ * (handeye.cpp:738-746 with sortStationMovements :615-663).  Inputs are n column-major 4x4
+ * transforms; outputs up to `cap` pairs of 4x4 transforms; *n_pairs receives the count
+ * (CVX_ERR_INVALID_ARG if cap is too small). */
+int cvx_handeye_pairs_fixed(int n, const double *gripper_to_base, const double *target_to_sensor,
+                            double *A, double *B, int cap, int *n_pairs);
+int cvx_handeye_pairs_moving(int n, const double *gripper_to_base, const double *target_to_sensor,
+                             double *A, double *B, int cap, int *n_pairs);
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic workloads of SURVEY.md section 8(d) (host only, deterministic)  */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int n_cameras, views_per_camera, board_w, board_h;   /* 9x6 -> 54 points, 12x9 -> 108 */
+    double tile;                                         /* 25 */
+    uint64_t seed;
+    double pixel_noise;                                  /* 0.1 */
+    int ragged;                                          /* 0: every marker visible; else drop ~1/ragged of them */
+} cvx_synth_calib_spec;
+
+/* sizes: n_views = n_cameras * views_per_camera, n_points = board_w * board_h */
+int64_t cvx_synth_calib_count(const cvx_synth_calib_spec *s);   /* number of observations */
+/* fills the problem arrays plus ground-truth and perturbed initial parameters */
+int cvx_synth_calib(const cvx_synth_calib_spec *s, int *cam_of_view, int *view_off, int *point_id,
+                    double *obs_x, double *obs_y, double *intr_gt, double *poses_gt, double *points_gt,
+                    double *intr_init, double *poses_init, double *points_init);
+
+/* n_poses gripper/target pose pairs obeying AX = XB up to noise; X_gt, X_init as p[7] */
+int cvx_synth_handeye(int n_poses, uint64_t seed, double rot_noise, double trans_noise,
+                      double *gripper_to_base /* n*16 */, double *target_to_sensor /* n*16 */,
+                      double x_gt[7], double x_init[7]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

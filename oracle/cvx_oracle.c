@@ -1,0 +1,1111 @@
+/*
+ * cvx_oracle.c -- CPU restatement of the cvx_calibration NLLS inner loop.
+ * TEST INFRASTRUCTURE ONLY (see cvx_oracle.h for scope, citations and the
+ * parity-pinning status).  Plain C99, no dependencies beyond libm.
+ */
+#include "cvx_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================== */
+/* forward-mode dual numbers (what a ceres::Jet<double,N> carries)           */
+/* ======================================================================== */
+#define ND 18
+typedef struct { double v; double d[ND]; } dual;
+
+static dual d_const(double c) { dual r; r.v = c; memset(r.d, 0, sizeof r.d); return r; }
+static dual d_var(double c, int k) { dual r = d_const(c); r.d[k] = 1.0; return r; }
+static dual d_add(dual a, dual b) { dual r; r.v = a.v + b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+static dual d_sub(dual a, dual b) { dual r; r.v = a.v - b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+static dual d_mul(dual a, dual b) { dual r; r.v = a.v * b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+static dual d_div(dual a, dual b) {
+    dual r; double inv = 1.0 / b.v; r.v = a.v * inv;
+    for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+static dual d_sqrt(dual a) { dual r; r.v = sqrt(a.v); double k = 0.5 / r.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * k; return r; }
+static dual d_sin(dual a) { dual r; r.v = sin(a.v); double k = cos(a.v); for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * k; return r; }
+static dual d_cos(dual a) { dual r; r.v = cos(a.v); double k = -sin(a.v); for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * k; return r; }
+
+/* ceres::AngleAxisRotatePoint (Ceres rotation.h; called at calibration.cpp:286) on duals */
+static void d_angle_axis_rotate_point(const dual w[3], const dual pt[3], dual out[3]) {
+    dual theta2 = d_add(d_add(d_mul(w[0], w[0]), d_mul(w[1], w[1])), d_mul(w[2], w[2]));
+    if (theta2.v > DBL_EPSILON) {
+        dual theta = d_sqrt(theta2);
+        dual c = d_cos(theta), s = d_sin(theta);
+        dual ti = d_div(d_const(1.0), theta);
+        dual a[3] = { d_mul(w[0], ti), d_mul(w[1], ti), d_mul(w[2], ti) };
+        dual wx[3] = { d_sub(d_mul(a[1], pt[2]), d_mul(a[2], pt[1])),
+                       d_sub(d_mul(a[2], pt[0]), d_mul(a[0], pt[2])),
+                       d_sub(d_mul(a[0], pt[1]), d_mul(a[1], pt[0])) };
+        dual tmp = d_mul(d_add(d_add(d_mul(a[0], pt[0]), d_mul(a[1], pt[1])), d_mul(a[2], pt[2])),
+                         d_sub(d_const(1.0), c));
+        for (int i = 0; i < 3; ++i)
+            out[i] = d_add(d_add(d_mul(pt[i], c), d_mul(wx[i], s)), d_mul(a[i], tmp));
+    } else {
+        dual wx[3] = { d_sub(d_mul(w[1], pt[2]), d_mul(w[2], pt[1])),
+                       d_sub(d_mul(w[2], pt[0]), d_mul(w[0], pt[2])),
+                       d_sub(d_mul(w[0], pt[1]), d_mul(w[1], pt[0])) };
+        for (int i = 0; i < 3; ++i) out[i] = d_add(pt[i], wx[i]);
+    }
+}
+
+/* calibration.cpp:231-257 + 266-311, evaluated on duals seeded over the 18 inputs */
+void orc_reproj_autodiff(const double intr[9], const double pose[6], const double X[3],
+                         double ox, double oy, double r[2],
+                         double Jc[18], double Jp[12], double Jx[6]) {
+    dual in[9], rt[6], pt[3];
+    for (int i = 0; i < 9; ++i) in[i] = d_var(intr[i], i);
+    for (int i = 0; i < 6; ++i) rt[i] = d_var(pose[i], 9 + i);
+    for (int i = 0; i < 3; ++i) pt[i] = d_var(X[i], 15 + i);
+    dual x[3];
+    d_angle_axis_rotate_point(rt, pt, x);
+    x[0] = d_add(x[0], rt[3]); x[1] = d_add(x[1], rt[4]); x[2] = d_add(x[2], rt[5]);
+    dual xn = d_div(x[0], x[2]), yn = d_div(x[1], x[2]);
+    dual two = d_const(2.0);
+    dual r2 = d_add(d_mul(xn, xn), d_mul(yn, yn));
+    dual r4 = d_mul(r2, r2);
+    dual r6 = d_mul(r4, r2);
+    dual rc = d_add(d_add(d_add(d_const(1.0), d_mul(in[ORC_K1], r2)), d_mul(in[ORC_K2], r4)), d_mul(in[ORC_K3], r6));
+    dual xd = d_add(d_add(d_mul(xn, rc), d_mul(d_mul(d_mul(two, in[ORC_P1]), xn), yn)),
+                    d_mul(in[ORC_P2], d_add(r2, d_mul(d_mul(two, xn), xn))));
+    dual yd = d_add(d_add(d_mul(yn, rc), d_mul(d_mul(d_mul(two, in[ORC_P2]), xn), yn)),
+                    d_mul(in[ORC_P1], d_add(r2, d_mul(d_mul(two, yn), yn))));
+    dual u = d_add(d_mul(in[ORC_FX], xd), in[ORC_CX]);
+    dual v = d_add(d_mul(in[ORC_FY], yd), in[ORC_CY]);
+    dual e[2] = { d_sub(u, d_const(ox)), d_sub(v, d_const(oy)) };
+    for (int k = 0; k < 2; ++k) {
+        r[k] = e[k].v;
+        if (Jc) for (int i = 0; i < 9; ++i) Jc[k * 9 + i] = e[k].d[i];
+        if (Jp) for (int i = 0; i < 6; ++i) Jp[k * 6 + i] = e[k].d[9 + i];
+        if (Jx) for (int i = 0; i < 3; ++i) Jx[k * 3 + i] = e[k].d[15 + i];
+    }
+}
+
+/* ======================================================================== */
+/* analytic reprojection residual + Jacobian                                 */
+/* ======================================================================== */
+/* x = AngleAxisRotatePoint(w, X) and G[i][j] = d x_i / d w_j (global derivative of the
+ * Rodrigues expression, both branches), Rm = d x / d X  (row-major 3x3) */
+static void rotate_point_jac(const double w[3], const double X[3], double x[3],
+                             double G[9], double Rm[9]) {
+    double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (theta2 > DBL_EPSILON) {
+        double theta = sqrt(theta2), c = cos(theta), s = sin(theta), ti = 1.0 / theta;
+        double a[3] = { w[0] * ti, w[1] * ti, w[2] * ti };
+        double ax[3] = { a[1] * X[2] - a[2] * X[1], a[2] * X[0] - a[0] * X[2], a[0] * X[1] - a[1] * X[0] };
+        double d = a[0] * X[0] + a[1] * X[1] + a[2] * X[2];
+        double omc = 1.0 - c;
+        for (int i = 0; i < 3; ++i) x[i] = X[i] * c + ax[i] * s + a[i] * (d * omc);
+        /* R = c I + s [a]x + (1-c) a a^T */
+        Rm[0] = c + omc * a[0] * a[0];        Rm[1] = -s * a[2] + omc * a[0] * a[1]; Rm[2] = s * a[1] + omc * a[0] * a[2];
+        Rm[3] = s * a[2] + omc * a[1] * a[0]; Rm[4] = c + omc * a[1] * a[1];         Rm[5] = -s * a[0] + omc * a[1] * a[2];
+        Rm[6] = -s * a[1] + omc * a[2] * a[0]; Rm[7] = s * a[0] + omc * a[2] * a[1]; Rm[8] = c + omc * a[2] * a[2];
+        for (int j = 0; j < 3; ++j) {
+            /* e_j x X */
+            double ex[3];
+            if (j == 0) { ex[0] = 0; ex[1] = -X[2]; ex[2] = X[1]; }
+            else if (j == 1) { ex[0] = X[2]; ex[1] = 0; ex[2] = -X[0]; }
+            else { ex[0] = -X[1]; ex[1] = X[0]; ex[2] = 0; }
+            for (int i = 0; i < 3; ++i) {
+                double t1 = a[j] * (-s * X[i] + c * ax[i] + s * d * a[i]);
+                double t2 = (s * ti) * (ex[i] - a[j] * ax[i]);
+                double ej_i = (i == j) ? 1.0 : 0.0;
+                double t3 = (omc * ti) * ((X[j] - a[j] * d) * a[i] + d * (ej_i - a[j] * a[i]));
+                G[i * 3 + j] = t1 + t2 + t3;
+            }
+        }
+    } else {
+        x[0] = X[0] + (w[1] * X[2] - w[2] * X[1]);
+        x[1] = X[1] + (w[2] * X[0] - w[0] * X[2]);
+        x[2] = X[2] + (w[0] * X[1] - w[1] * X[0]);
+        Rm[0] = 1; Rm[1] = -w[2]; Rm[2] = w[1];
+        Rm[3] = w[2]; Rm[4] = 1; Rm[5] = -w[0];
+        Rm[6] = -w[1]; Rm[7] = w[0]; Rm[8] = 1;
+        /* d(w x X)/dw_j = e_j x X */
+        G[0] = 0;     G[1] = X[2];  G[2] = -X[1];
+        G[3] = -X[2]; G[4] = 0;     G[5] = X[0];
+        G[6] = X[1];  G[7] = -X[0]; G[8] = 0;
+    }
+}
+
+void orc_reproj_analytic(const double intr[9], const double pose[6], const double X[3],
+                         double ox, double oy, double r[2],
+                         double Jc[18], double Jp[12], double Jx[6]) {
+    double xc[3], G[9], Rm[9];
+    rotate_point_jac(pose, X, xc, G, Rm);
+    xc[0] += pose[3]; xc[1] += pose[4]; xc[2] += pose[5];
+    const double fx = intr[ORC_FX], fy = intr[ORC_FY], cx = intr[ORC_CX], cy = intr[ORC_CY];
+    const double k1 = intr[ORC_K1], k2 = intr[ORC_K2], k3 = intr[ORC_K3], p1 = intr[ORC_P1], p2 = intr[ORC_P2];
+    double xn = xc[0] / xc[2], yn = xc[1] / xc[2];
+    double r2 = xn * xn + yn * yn, r4 = r2 * r2, r6 = r4 * r2;
+    double rc = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    double xd = xn * rc + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);
+    double yd = yn * rc + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);
+    r[0] = fx * xd + cx - ox;
+    r[1] = fy * yd + cy - oy;
+    if (!Jc && !Jp && !Jx) return;
+    if (Jc) {
+        double *a = Jc, *b = Jc + 9;
+        a[ORC_FX] = xd;  b[ORC_FX] = 0;
+        a[ORC_FY] = 0;   b[ORC_FY] = yd;
+        a[ORC_CX] = 1;   b[ORC_CX] = 0;
+        a[ORC_CY] = 0;   b[ORC_CY] = 1;
+        a[ORC_K1] = fx * xn * r2; b[ORC_K1] = fy * yn * r2;
+        a[ORC_K2] = fx * xn * r4; b[ORC_K2] = fy * yn * r4;
+        a[ORC_K3] = fx * xn * r6; b[ORC_K3] = fy * yn * r6;
+        a[ORC_P1] = fx * 2.0 * xn * yn;           b[ORC_P1] = fy * (r2 + 2.0 * yn * yn);
+        a[ORC_P2] = fx * (r2 + 2.0 * xn * xn);    b[ORC_P2] = fy * 2.0 * xn * yn;
+    }
+    /* d(xd,yd)/d(xn,yn) */
+    double rcp = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+    double dxx = rc + 2.0 * xn * xn * rcp + 2.0 * p1 * yn + 6.0 * p2 * xn;
+    double dxy = 2.0 * xn * yn * rcp + 2.0 * p1 * xn + 2.0 * p2 * yn;
+    double dyy = rc + 2.0 * yn * yn * rcp + 2.0 * p2 * xn + 6.0 * p1 * yn;
+    double iz = 1.0 / xc[2];
+    double a11 = fx * dxx, a12 = fx * dxy, a21 = fy * dxy, a22 = fy * dyy;
+    double D[6] = { a11 * iz, a12 * iz, -(a11 * xn + a12 * yn) * iz,
+                    a21 * iz, a22 * iz, -(a21 * xn + a22 * yn) * iz };
+    if (Jp) for (int k = 0; k < 2; ++k) {
+        for (int j = 0; j < 3; ++j)
+            Jp[k * 6 + j] = D[k * 3 + 0] * G[0 * 3 + j] + D[k * 3 + 1] * G[1 * 3 + j] + D[k * 3 + 2] * G[2 * 3 + j];
+        for (int j = 0; j < 3; ++j) Jp[k * 6 + 3 + j] = D[k * 3 + j];
+    }
+    if (Jx) for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 3; ++j)
+            Jx[k * 3 + j] = D[k * 3 + 0] * Rm[0 * 3 + j] + D[k * 3 + 1] * Rm[1 * 3 + j] + D[k * 3 + 2] * Rm[2 * 3 + j];
+}
+
+/* ======================================================================== */
+/* Ceres rotation helpers used by pack/unpack (calibration.cpp:318-350)      */
+/* ======================================================================== */
+void orc_angle_axis_to_rotation(const double w[3], double R[9]) {
+#define RR(i, j) R[(j) * 3 + (i)]
+    double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (theta2 > DBL_EPSILON) {
+        double theta = sqrt(theta2);
+        double wx = w[0] / theta, wy = w[1] / theta, wz = w[2] / theta;
+        double c = cos(theta), s = sin(theta);
+        RR(0, 0) = c + wx * wx * (1.0 - c);
+        RR(1, 0) = wz * s + wx * wy * (1.0 - c);
+        RR(2, 0) = -wy * s + wx * wz * (1.0 - c);
+        RR(0, 1) = wx * wy * (1.0 - c) - wz * s;
+        RR(1, 1) = c + wy * wy * (1.0 - c);
+        RR(2, 1) = wx * s + wy * wz * (1.0 - c);
+        RR(0, 2) = wy * s + wx * wz * (1.0 - c);
+        RR(1, 2) = -wx * s + wy * wz * (1.0 - c);
+        RR(2, 2) = c + wz * wz * (1.0 - c);
+    } else {
+        RR(0, 0) = 1; RR(1, 0) = w[2]; RR(2, 0) = -w[1];
+        RR(0, 1) = -w[2]; RR(1, 1) = 1; RR(2, 1) = w[0];
+        RR(0, 2) = w[1]; RR(1, 2) = -w[0]; RR(2, 2) = 1;
+    }
+}
+
+void orc_rotation_to_angle_axis(const double R[9], double w[3]) {
+    /* RotationMatrixToQuaternion followed by QuaternionToAngleAxis */
+    double q[4];
+    double trace = RR(0, 0) + RR(1, 1) + RR(2, 2);
+    if (trace >= 0.0) {
+        double t = sqrt(trace + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[1] = (RR(2, 1) - RR(1, 2)) * t;
+        q[2] = (RR(0, 2) - RR(2, 0)) * t;
+        q[3] = (RR(1, 0) - RR(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (RR(1, 1) > RR(0, 0)) i = 1;
+        if (RR(2, 2) > RR(i, i)) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        double t = sqrt(RR(i, i) - RR(j, j) - RR(k, k) + 1.0);
+        q[i + 1] = 0.5 * t; t = 0.5 / t;
+        q[0] = (RR(k, j) - RR(j, k)) * t;
+        q[j + 1] = (RR(j, i) + RR(i, j)) * t;
+        q[k + 1] = (RR(k, i) + RR(i, k)) * t;
+    }
+    double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (s2 > 0.0) {
+        double st = sqrt(s2), ct = q[0];
+        double two_theta = 2.0 * ((ct < 0.0) ? atan2(-st, -ct) : atan2(st, ct));
+        double k = two_theta / st;
+        w[0] = q[1] * k; w[1] = q[2] * k; w[2] = q[3] * k;
+    } else {
+        w[0] = q[1] * 2.0; w[1] = q[2] * 2.0; w[2] = q[3] * 2.0;
+    }
+#undef RR
+}
+
+void orc_quaternion_plus(const double x[4], const double delta[3], double out[4]) {
+    double n = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+    if (n > 0.0) {
+        double sn = sin(n) / n;
+        double q[4] = { cos(n), sn * delta[0], sn * delta[1], sn * delta[2] };
+        /* q (x) x, Hamilton product */
+        out[0] = q[0] * x[0] - q[1] * x[1] - q[2] * x[2] - q[3] * x[3];
+        out[1] = q[0] * x[1] + q[1] * x[0] + q[2] * x[3] - q[3] * x[2];
+        out[2] = q[0] * x[2] - q[1] * x[3] + q[2] * x[0] + q[3] * x[1];
+        out[3] = q[0] * x[3] + q[1] * x[2] - q[2] * x[1] + q[3] * x[0];
+    } else {
+        for (int i = 0; i < 4; ++i) out[i] = x[i];
+    }
+}
+
+/* ======================================================================== */
+/* hand-eye PoseError2                                                       */
+/* ======================================================================== */
+/* Eigen QuaternionBase::toRotationMatrix, no normalisation, row-major out */
+static void quat_to_R(const double q[4], double R[9]) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    double twx = tx * w, twy = ty * w, twz = tz * w;
+    double txx = tx * x, txy = ty * x, txz = tz * x;
+    double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+/* dR/dq_k, k = w,x,y,z, row-major */
+static void quat_dR(const double q[4], double dR[4][9]) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    double dw[9] = { 0, -2 * z, 2 * y,   2 * z, 0, -2 * x,   -2 * y, 2 * x, 0 };
+    double dx[9] = { 0, 2 * y, 2 * z,    2 * y, -4 * x, -2 * w,   2 * z, 2 * w, -4 * x };
+    double dy[9] = { -4 * y, 2 * x, 2 * w,   2 * x, 0, 2 * z,   -2 * w, 2 * z, -4 * y };
+    double dz[9] = { -4 * z, -2 * w, 2 * x,   2 * w, -4 * z, 2 * y,   2 * x, 2 * y, 0 };
+    memcpy(dR[0], dw, sizeof dw); memcpy(dR[1], dx, sizeof dx);
+    memcpy(dR[2], dy, sizeof dy); memcpy(dR[3], dz, sizeof dz);
+}
+static void mat3_mul(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+        C[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
+}
+
+void orc_handeye_analytic(const double q[4], const double t[3],
+                          const double qa[4], const double ta[3],
+                          const double qb[4], const double tb[3],
+                          double r[12], double Jq[48], double Jt[36]) {
+    double Rx[9], Ra[9], Rb[9], A[9], B[9];
+    quat_to_R(q, Rx); quat_to_R(qa, Ra); quat_to_R(qb, Rb);
+    mat3_mul(Ra, Rx, A); mat3_mul(Rx, Rb, B);
+    for (int i = 0; i < 9; ++i) r[i] = A[i] - B[i];
+    for (int i = 0; i < 3; ++i) {
+        double rat = Ra[i * 3] * t[0] + Ra[i * 3 + 1] * t[1] + Ra[i * 3 + 2] * t[2];
+        double rxt = Rx[i * 3] * tb[0] + Rx[i * 3 + 1] * tb[1] + Rx[i * 3 + 2] * tb[2];
+        r[9 + i] = rat + ta[i] - rxt - t[i];
+    }
+    if (Jq) {
+        double dR[4][9];
+        quat_dR(q, dR);
+        for (int k = 0; k < 4; ++k) {
+            mat3_mul(Ra, dR[k], A); mat3_mul(dR[k], Rb, B);
+            for (int i = 0; i < 9; ++i) Jq[i * 4 + k] = A[i] - B[i];
+            for (int i = 0; i < 3; ++i)
+                Jq[(9 + i) * 4 + k] = -(dR[k][i * 3] * tb[0] + dR[k][i * 3 + 1] * tb[1] + dR[k][i * 3 + 2] * tb[2]);
+        }
+    }
+    if (Jt) {
+        memset(Jt, 0, 36 * sizeof(double));
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+            Jt[(9 + i) * 3 + j] = Ra[i * 3 + j] - (i == j ? 1.0 : 0.0);
+    }
+}
+
+static void d_quat_to_R(const dual q[4], dual R[9]) {
+    dual w = q[0], x = q[1], y = q[2], z = q[3], two = d_const(2.0), one = d_const(1.0);
+    dual tx = d_mul(two, x), ty = d_mul(two, y), tz = d_mul(two, z);
+    dual twx = d_mul(tx, w), twy = d_mul(ty, w), twz = d_mul(tz, w);
+    dual txx = d_mul(tx, x), txy = d_mul(ty, x), txz = d_mul(tz, x);
+    dual tyy = d_mul(ty, y), tyz = d_mul(tz, y), tzz = d_mul(tz, z);
+    R[0] = d_sub(one, d_add(tyy, tzz)); R[1] = d_sub(txy, twz); R[2] = d_add(txz, twy);
+    R[3] = d_add(txy, twz); R[4] = d_sub(one, d_add(txx, tzz)); R[5] = d_sub(tyz, twx);
+    R[6] = d_sub(txz, twy); R[7] = d_add(tyz, twx); R[8] = d_sub(one, d_add(txx, tyy));
+}
+
+void orc_handeye_autodiff(const double q[4], const double t[3],
+                          const double qa[4], const double ta[3],
+                          const double qb[4], const double tb[3],
+                          double r[12], double Jq[48], double Jt[36]) {
+    dual dq[4], dt[3], Rx[9];
+    for (int i = 0; i < 4; ++i) dq[i] = d_var(q[i], i);
+    for (int i = 0; i < 3; ++i) dt[i] = d_var(t[i], 4 + i);
+    d_quat_to_R(dq, Rx);
+    double Ra[9], Rb[9];
+    quat_to_R(qa, Ra); quat_to_R(qb, Rb);
+    dual res[12];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        dual a = d_const(0.0), b = d_const(0.0);
+        for (int k = 0; k < 3; ++k) {
+            a = d_add(a, d_mul(d_const(Ra[i * 3 + k]), Rx[k * 3 + j]));
+            b = d_add(b, d_mul(Rx[i * 3 + k], d_const(Rb[k * 3 + j])));
+        }
+        res[i * 3 + j] = d_sub(a, b);
+    }
+    for (int i = 0; i < 3; ++i) {
+        dual a = d_const(ta[i]), b = d_const(0.0);
+        for (int k = 0; k < 3; ++k) {
+            a = d_add(a, d_mul(d_const(Ra[i * 3 + k]), dt[k]));
+            b = d_add(b, d_mul(Rx[i * 3 + k], d_const(tb[k])));
+        }
+        res[9 + i] = d_sub(d_sub(a, b), dt[i]);
+    }
+    for (int i = 0; i < 12; ++i) {
+        r[i] = res[i].v;
+        if (Jq) for (int k = 0; k < 4; ++k) Jq[i * 4 + k] = res[i].d[k];
+        if (Jt) for (int k = 0; k < 3; ++k) Jt[i * 3 + k] = res[i].d[4 + k];
+    }
+}
+
+/* ======================================================================== */
+/* dense SPD solve                                                           */
+/* ======================================================================== */
+int orc_cholesky_solve(int n, double *A, double *b) {
+    /* A = L L^T in the lower triangle, row-major */
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s -= A[j * n + k] * A[j * n + k];
+        if (!(s > 0.0) || !isfinite(s)) return 0;
+        double l = sqrt(s);
+        A[j * n + j] = l;
+        double inv = 1.0 / l;
+        for (int i = j + 1; i < n; ++i) {
+            double t = A[i * n + j];
+            const double *ai = A + i * n, *aj = A + j * n;
+            for (int k = 0; k < j; ++k) t -= ai[k] * aj[k];
+            A[i * n + j] = t * inv;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        double t = b[i];
+        for (int k = 0; k < i; ++k) t -= A[i * n + k] * b[k];
+        b[i] = t / A[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double t = b[i];
+        for (int k = i + 1; k < n; ++k) t -= A[k * n + i] * b[k];
+        b[i] = t / A[i * n + i];
+    }
+    return 1;
+}
+
+/* ======================================================================== */
+/* LM options                                                                */
+/* ======================================================================== */
+static void lm_defaults(orc_lm_options *o) {
+    memset(o, 0, sizeof *o);
+    o->strategy = 0;
+    o->max_iterations = 50;             /* Ceres default */
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->initial_radius = 1e4;
+    o->max_radius = 1e16;
+    o->min_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->jacobi_scaling = 1;
+    o->nonmonotonic = 0;
+    o->max_consecutive_nonmonotonic_steps = 5;
+    o->tau = 1e-3; o->eps1 = o->eps2 = o->eps3 = 1e-17;   /* levmar.h:90-91 */
+}
+void orc_lm_options_refine(orc_lm_options *o) {   /* calibration.cpp:420-428 */
+    lm_defaults(o);
+    o->nonmonotonic = 1;
+    o->max_iterations = 100;
+    o->function_tolerance = 1e-10;
+    o->gradient_tolerance = 1e-10;
+}
+void orc_lm_options_handeye(orc_lm_options *o) {  /* handeye.cpp:310-319 */
+    lm_defaults(o);
+    o->max_iterations = 100;
+}
+void orc_lm_options_levmar(orc_lm_options *o) {   /* lm.hpp:43-50,61 */
+    lm_defaults(o);
+    o->strategy = 1;
+    o->max_iterations = 100;
+    o->tau = 1e-3;
+    o->eps1 = DBL_EPSILON; o->eps2 = DBL_EPSILON; o->eps3 = DBL_EPSILON;
+}
+
+/* ======================================================================== */
+/* generic LM drivers over a linearisable model                              */
+/* ======================================================================== */
+typedef struct {
+    void *ctx;
+    int nfree, nglobal;
+    /* linearise at x: diag of J^T J and gradient J^T r over the tangent space; returns cost */
+    double (*linearize)(void *ctx, const double *x, double *diag, double *grad);
+    /* solve (J^T J + diag(D)) delta = -grad for the last linearisation */
+    int (*solve)(void *ctx, const double *D, double *delta);
+    void (*plus)(void *ctx, const double *x, const double *delta, double *xout);
+    double (*cost)(void *ctx, const double *x);
+    double (*free_norm2)(void *ctx, const double *x);   /* Nielsen's ||p||^2 */
+} lm_model;
+
+static void trace_push(orc_lm_summary *s, double cost, int acc, double damp, double grad) {
+    if (s->trace_len < ORC_TRACE_MAX) {
+        s->trace_cost[s->trace_len] = cost;
+        s->trace_accepted[s->trace_len] = acc;
+        s->trace_damping[s->trace_len] = damp;
+        s->trace_gradient[s->trace_len] = grad;
+        s->trace_len++;
+    }
+}
+
+static double vec_norm(const double *a, int n) { double s = 0; for (int i = 0; i < n; ++i) s += a[i] * a[i]; return sqrt(s); }
+
+/* max-norm of x - Plus(x, -g): Ceres' projected gradient norm */
+static double gradient_max_norm(const lm_model *m, const double *x, const double *g, double *tmpd, double *tmpx) {
+    for (int i = 0; i < m->nfree; ++i) tmpd[i] = -g[i];
+    m->plus(m->ctx, x, tmpd, tmpx);
+    double mx = 0;
+    for (int i = 0; i < m->nglobal; ++i) { double a = fabs(x[i] - tmpx[i]); if (a > mx) mx = a; }
+    return mx;
+}
+
+/* Ceres-style Levenberg-Marquardt trust region (TrustRegionMinimizer +
+ * LevenbergMarquardtStrategy + TrustRegionStepEvaluator), restated from the
+ * published algorithm; inner iterations are not restated. */
+static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_lm_summary *sum) {
+    const int nf = m->nfree, ng = m->nglobal;
+    double *diag = malloc(sizeof(double) * nf), *grad = malloc(sizeof(double) * nf);
+    double *s2 = malloc(sizeof(double) * nf), *D = malloc(sizeof(double) * nf);
+    double *delta = malloc(sizeof(double) * nf), *tmpd = malloc(sizeof(double) * nf);
+    double *xc = malloc(sizeof(double) * ng), *tmpx = malloc(sizeof(double) * ng);
+    memset(sum, 0, sizeof *sum);
+
+    double cost = m->linearize(m->ctx, x, diag, grad);
+    sum->initial_cost = cost;
+    for (int i = 0; i < nf; ++i) {
+        if (o->jacobi_scaling) { double s = 1.0 / (1.0 + sqrt(diag[i])); s2[i] = s * s; }
+        else s2[i] = 1.0;
+    }
+    double gmax = gradient_max_norm(m, x, grad, tmpd, tmpx);
+    double radius = o->initial_radius, decrease_factor = 2.0;
+    /* TrustRegionStepEvaluator state */
+    double ev_min = cost, ev_cur = cost, ev_ref = cost, ev_cand = cost;
+    double ev_acc_ref = 0, ev_acc_cand = 0; int ev_nonmono = 0;
+    const int max_nonmono = o->nonmonotonic ? o->max_consecutive_nonmonotonic_steps : 0;
+    int term = 0, invalid_run = 0;
+    if (gmax <= o->gradient_tolerance) term = 1;
+
+    int it = 0;
+    while (!term) {
+        if (it >= o->max_iterations) { term = 4; break; }
+        ++it;
+        for (int i = 0; i < nf; ++i) {
+            double d = s2[i] * diag[i];
+            if (d < o->min_lm_diagonal) d = o->min_lm_diagonal;
+            if (d > o->max_lm_diagonal) d = o->max_lm_diagonal;
+            D[i] = d / (s2[i] * radius);
+        }
+        int ok = m->solve(m->ctx, D, delta);
+        sum->num_linear_solves++;
+        double model_change = 0;
+        if (ok) {
+            for (int i = 0; i < nf; ++i) model_change += delta[i] * (D[i] * delta[i] - grad[i]);
+            model_change *= 0.5;
+        }
+        if (!ok || !(model_change > 0.0)) {
+            /* HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid */
+            trace_push(sum, NAN, 0, radius, gmax);
+            if (++invalid_run >= 5) { term = 6; break; }
+            radius *= 0.5;
+            continue;
+        }
+        invalid_run = 0;
+        m->plus(m->ctx, x, delta, xc);
+        double cand = m->cost(m->ctx, xc);
+        /* step / x norms in the global parameter space */
+        double sn = 0; for (int i = 0; i < ng; ++i) { double d = x[i] - xc[i]; sn += d * d; } sn = sqrt(sn);
+        double xn = vec_norm(x, ng);
+        if (sn <= o->parameter_tolerance * (xn + o->parameter_tolerance)) {
+            trace_push(sum, cand, 0, radius, gmax);
+            term = 2; break;
+        }
+        if (fabs(cost - cand) <= o->function_tolerance * cost) {
+            trace_push(sum, cand, 0, radius, gmax);
+            term = 3; break;
+        }
+        /* StepQuality */
+        double rel = (ev_cur - cand) / model_change;
+        double hist = (ev_ref - cand) / (ev_acc_ref + model_change);
+        double rho = (max_nonmono > 0 && hist > rel) ? hist : rel;
+        if (rho > o->min_relative_decrease) {
+            trace_push(sum, cand, 1, radius, gmax);
+            memcpy(x, xc, sizeof(double) * ng);
+            /* LevenbergMarquardtStrategy::StepAccepted */
+            double t = 2.0 * rho - 1.0;
+            double f = 1.0 - t * t * t; if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+            radius = radius / f; if (radius > o->max_radius) radius = o->max_radius;
+            decrease_factor = 2.0;
+            /* TrustRegionStepEvaluator::StepAccepted */
+            ev_cur = cand; ev_acc_cand += model_change; ev_acc_ref += model_change;
+            if (ev_cur < ev_min) { ev_min = ev_cur; ev_nonmono = 0; ev_cand = ev_cur; ev_acc_cand = 0; }
+            else { ++ev_nonmono; if (ev_cur > ev_cand) { ev_cand = ev_cur; ev_acc_cand = 0; } }
+            if (ev_nonmono == max_nonmono) { ev_ref = ev_cand; ev_acc_ref = ev_acc_cand; }
+            sum->num_successful++;
+            cost = m->linearize(m->ctx, x, diag, grad);
+            gmax = gradient_max_norm(m, x, grad, tmpd, tmpx);
+            if (gmax <= o->gradient_tolerance) { term = 1; break; }
+        } else {
+            trace_push(sum, cand, 0, radius, gmax);
+            radius = radius / decrease_factor; decrease_factor *= 2.0;
+            if (radius < o->min_radius) { term = 5; break; }
+        }
+    }
+    sum->iterations = it; sum->termination = term; sum->final_cost = cost;
+    free(diag); free(grad); free(s2); free(D); free(delta); free(tmpd); free(xc); free(tmpx);
+    return term;
+}
+
+/* levmar dlevmar_der control flow, lm_core.c:163-409, over the same model
+ * interface (the linear algebra is the model's; damping is mu * I). */
+static int lm_nielsen(const lm_model *m, double *x, const orc_lm_options *o, orc_lm_summary *sum) {
+    const int nf = m->nfree, ng = m->nglobal;
+    double *diag = malloc(sizeof(double) * nf), *grad = malloc(sizeof(double) * nf);
+    double *D = malloc(sizeof(double) * nf), *delta = malloc(sizeof(double) * nf);
+    double *xc = malloc(sizeof(double) * ng);
+    memset(sum, 0, sizeof *sum);
+    double mu = 0, eps2_sq = o->eps2 * o->eps2;
+    int nu = 2, stop = 0, k;
+    double p_eL2 = 2.0 * m->cost(m->ctx, x);
+    sum->initial_cost = 0.5 * p_eL2;
+    if (!isfinite(p_eL2)) stop = 7;
+    for (k = 0; k < o->max_iterations && !stop; ++k) {
+        if (p_eL2 <= o->eps3) { stop = 6; break; }
+        m->linearize(m->ctx, x, diag, grad);
+        double ginf = 0; for (int i = 0; i < nf; ++i) { double a = fabs(grad[i]); if (a > ginf) ginf = a; }
+        double p_L2 = m->free_norm2(m->ctx, x);
+        if (ginf <= o->eps1) { stop = 1; break; }
+        if (k == 0) {
+            double mx = DBL_MIN; for (int i = 0; i < nf; ++i) if (diag[i] > mx) mx = diag[i];
+            mu = o->tau * mx;
+        }
+        for (;;) {
+            for (int i = 0; i < nf; ++i) D[i] = mu;
+            int ok = m->solve(m->ctx, D, delta);
+            sum->num_linear_solves++;
+            if (ok) {
+                double Dp_L2 = 0; for (int i = 0; i < nf; ++i) Dp_L2 += delta[i] * delta[i];
+                if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
+                if (Dp_L2 >= (p_L2 + o->eps2) / (DBL_EPSILON * DBL_EPSILON)) { stop = 4; break; }
+                m->plus(m->ctx, x, delta, xc);
+                double pDp_eL2 = 2.0 * m->cost(m->ctx, xc);
+                if (!isfinite(pDp_eL2)) { stop = 7; break; }
+                double dL = 0; for (int i = 0; i < nf; ++i) dL += delta[i] * (mu * delta[i] - grad[i]);
+                double dF = p_eL2 - pDp_eL2;
+                if (dL > 0.0 && dF > 0.0) {
+                    trace_push(sum, 0.5 * pDp_eL2, 1, mu, ginf);
+                    double t = 2.0 * dF / dL - 1.0; t = 1.0 - t * t * t;
+                    mu = mu * ((t >= 1.0 / 3.0) ? t : 1.0 / 3.0);
+                    nu = 2;
+                    memcpy(x, xc, sizeof(double) * ng);
+                    p_eL2 = pDp_eL2;
+                    sum->num_successful++;
+                    break;
+                }
+                trace_push(sum, 0.5 * pDp_eL2, 0, mu, ginf);
+            } else {
+                trace_push(sum, NAN, 0, mu, ginf);
+            }
+            mu *= nu;
+            int nu2 = nu << 1;
+            if (nu2 <= nu) { stop = 5; break; }
+            nu = nu2;
+        }
+    }
+    if (k >= o->max_iterations && !stop) stop = 3;
+    sum->iterations = k; sum->termination = stop; sum->final_cost = 0.5 * p_eL2;
+    free(diag); free(grad); free(D); free(delta); free(xc);
+    return stop;
+}
+
+/* ======================================================================== */
+/* calibration problem                                                       */
+/* ======================================================================== */
+static int n_cam_free(const orc_calib_problem *pb) { return pb->fix_intrinsics ? 0 : (pb->fix_k3 ? 8 : 9); }
+/* free column k (0..nci-1) -> intrinsics index */
+static int cam_col(const orc_calib_problem *pb, int k) { return (pb->fix_k3 && k >= ORC_K3) ? k + 1 : k; }
+
+int orc_calib_num_shared(const orc_calib_problem *pb) {
+    return pb->C * n_cam_free(pb) + (pb->fix_points ? 0 : 3 * pb->P);
+}
+int orc_calib_num_free(const orc_calib_problem *pb) { return orc_calib_num_shared(pb) + 6 * pb->V; }
+
+double orc_calib_cost(const orc_calib_problem *pb, const double *intr, const double *poses,
+                      const double *points) {
+    double s = 0;
+    for (int v = 0; v < pb->V; ++v) {
+        const double *in = intr + 9 * pb->cam_of_view[v];
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            double r[2];
+            orc_reproj_analytic(in, poses + 6 * v, points + 3 * pb->point_id[o], pb->obs_x[o], pb->obs_y[o], r, 0, 0, 0);
+            s += r[0] * r[0] + r[1] * r[1];
+        }
+    }
+    return 0.5 * s;
+}
+
+void orc_calib_eval(const orc_calib_problem *pb, const double *intr, const double *poses,
+                    const double *points, double *r, double *Jc, double *Jp, double *Jx) {
+    for (int v = 0; v < pb->V; ++v) {
+        const double *in = intr + 9 * pb->cam_of_view[v];
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            double rr[2];
+            orc_reproj_analytic(in, poses + 6 * v, points + 3 * pb->point_id[o], pb->obs_x[o], pb->obs_y[o], rr,
+                                Jc ? Jc + 18 * (size_t)o : 0, Jp ? Jp + 12 * (size_t)o : 0, Jx ? Jx + 6 * (size_t)o : 0);
+            if (r) { r[2 * (size_t)o] = rr[0]; r[2 * (size_t)o + 1] = rr[1]; }
+        }
+    }
+}
+
+void orc_calib_dense_jacobian(const orc_calib_problem *pb, const double *intr,
+                              const double *poses, const double *points, double *J) {
+    const int nci = n_cam_free(pb), m = orc_calib_num_free(pb);
+    const int off_pose = pb->C * nci, off_pt = off_pose + 6 * pb->V;
+    memset(J, 0, sizeof(double) * (size_t)2 * pb->N * m);
+    for (int v = 0; v < pb->V; ++v) {
+        int c = pb->cam_of_view[v];
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            double r[2], Jc[18], Jp[12], Jx[6];
+            int pid = pb->point_id[o];
+            orc_reproj_analytic(intr + 9 * c, poses + 6 * v, points + 3 * pid, pb->obs_x[o], pb->obs_y[o], r, Jc, Jp, Jx);
+            for (int k = 0; k < 2; ++k) {
+                double *row = J + (size_t)(2 * o + k) * m;
+                for (int i = 0; i < nci; ++i) row[c * nci + i] = Jc[k * 9 + cam_col(pb, i)];
+                for (int i = 0; i < 6; ++i) row[off_pose + 6 * v + i] = Jp[k * 6 + i];
+                if (!pb->fix_points) for (int i = 0; i < 3; ++i) row[off_pt + 3 * pid + i] = Jx[k * 3 + i];
+            }
+        }
+    }
+}
+
+/* compact Schur storage for one linearisation */
+typedef struct {
+    const orc_calib_problem *pb;
+    int nci, ns, off_pt;      /* shared ordering: [cams | points] */
+    double *Vv, *gv;          /* [V*36], [V*6] */
+    double *Wc;               /* [V*6*nci] pose x own-camera block */
+    double *Wx;               /* [N*18]   pose x point block per observation (6x3) */
+    double *U, *gs;           /* [ns*ns], [ns] */
+    double *S, *rhs, *T;      /* scratch: reduced system, rhs, per-view V^-1 W */
+    double *Dcur;             /* damping used by the last solve */
+    double cost;
+} calib_lin;
+
+static void calib_lin_alloc(calib_lin *L, const orc_calib_problem *pb) {
+    L->pb = pb; L->nci = n_cam_free(pb); L->ns = orc_calib_num_shared(pb); L->off_pt = pb->C * L->nci;
+    L->Vv = malloc(sizeof(double) * 36 * pb->V); L->gv = malloc(sizeof(double) * 6 * pb->V);
+    L->Wc = malloc(sizeof(double) * 6 * (L->nci ? L->nci : 1) * pb->V);
+    L->Wx = malloc(sizeof(double) * 18 * (size_t)pb->N);
+    int ns = L->ns ? L->ns : 1;
+    L->U = malloc(sizeof(double) * (size_t)ns * ns); L->gs = malloc(sizeof(double) * ns);
+    L->S = malloc(sizeof(double) * (size_t)ns * ns); L->rhs = malloc(sizeof(double) * ns);
+    L->T = malloc(sizeof(double) * 6 * ns);
+    L->Dcur = malloc(sizeof(double) * (L->ns + 6 * pb->V));
+}
+static void calib_lin_free(calib_lin *L) {
+    free(L->Vv); free(L->gv); free(L->Wc); free(L->Wx); free(L->U); free(L->gs);
+    free(L->S); free(L->rhs); free(L->T); free(L->Dcur);
+}
+
+static void calib_linearize_blocks(calib_lin *L, const double *intr, const double *poses, const double *points) {
+    const orc_calib_problem *pb = L->pb;
+    const int nci = L->nci, ns = L->ns, fixp = pb->fix_points;
+    memset(L->U, 0, sizeof(double) * (size_t)ns * ns); memset(L->gs, 0, sizeof(double) * ns);
+    double cost = 0;
+    for (int v = 0; v < pb->V; ++v) {
+        int c = pb->cam_of_view[v];
+        double *Vv = L->Vv + 36 * v, *gv = L->gv + 6 * v, *Wc = L->Wc + (size_t)6 * nci * v;
+        memset(Vv, 0, 36 * sizeof(double)); memset(gv, 0, 6 * sizeof(double));
+        memset(Wc, 0, sizeof(double) * 6 * nci);
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            double r[2], Jc9[18], Jp[12], Jx[6], Jc[18];
+            int pid = pb->point_id[o];
+            orc_reproj_analytic(intr + 9 * c, poses + 6 * v, points + 3 * pid, pb->obs_x[o], pb->obs_y[o], r, Jc9, Jp, Jx);
+            for (int k = 0; k < 2; ++k) for (int i = 0; i < nci; ++i) Jc[k * nci + i] = Jc9[k * 9 + cam_col(pb, i)];
+            cost += r[0] * r[0] + r[1] * r[1];
+            double *Wx = L->Wx + 18 * (size_t)o;
+            memset(Wx, 0, 18 * sizeof(double));
+            for (int k = 0; k < 2; ++k) {
+                const double *jp = Jp + 6 * k, *jc = Jc + nci * k, *jx = Jx + 3 * k;
+                for (int a = 0; a < 6; ++a) {
+                    for (int b = 0; b < 6; ++b) Vv[a * 6 + b] += jp[a] * jp[b];
+                    gv[a] += jp[a] * r[k];
+                    for (int b = 0; b < nci; ++b) Wc[a * nci + b] += jp[a] * jc[b];
+                    if (!fixp) for (int b = 0; b < 3; ++b) Wx[a * 3 + b] += jp[a] * jx[b];
+                }
+                for (int a = 0; a < nci; ++a) {
+                    int ia = c * nci + a;
+                    for (int b = 0; b < nci; ++b) L->U[(size_t)ia * ns + c * nci + b] += jc[a] * jc[b];
+                    L->gs[ia] += jc[a] * r[k];
+                    if (!fixp) for (int b = 0; b < 3; ++b) {
+                        int ib = L->off_pt + 3 * pid + b;
+                        L->U[(size_t)ia * ns + ib] += jc[a] * jx[b];
+                        L->U[(size_t)ib * ns + ia] += jc[a] * jx[b];
+                    }
+                }
+                if (!fixp) for (int a = 0; a < 3; ++a) {
+                    int ia = L->off_pt + 3 * pid + a;
+                    for (int b = 0; b < 3; ++b) L->U[(size_t)ia * ns + L->off_pt + 3 * pid + b] += jx[a] * jx[b];
+                    L->gs[ia] += jx[a] * r[k];
+                }
+            }
+        }
+    }
+    L->cost = 0.5 * cost;
+}
+
+/* 6x6 SPD inverse-apply helper: Cholesky factor in place (lower), returns 0 if not PD */
+static int chol6(double A[36]) {
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) s -= A[j * 6 + k] * A[j * 6 + k];
+        if (!(s > 0.0) || !isfinite(s)) return 0;
+        double l = sqrt(s); A[j * 6 + j] = l;
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) t -= A[i * 6 + k] * A[j * 6 + k];
+            A[i * 6 + j] = t / l;
+        }
+    }
+    return 1;
+}
+static void chol6_solve(const double L[36], double *b, int stride) {
+    for (int i = 0; i < 6; ++i) {
+        double t = b[i * stride];
+        for (int k = 0; k < i; ++k) t -= L[i * 6 + k] * b[k * stride];
+        b[i * stride] = t / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double t = b[i * stride];
+        for (int k = i + 1; k < 6; ++k) t -= L[k * 6 + i] * b[k * stride];
+        b[i * stride] = t / L[i * 6 + i];
+    }
+}
+
+/* Builds S and rhs for damping D = [Ds (ns) | Dp (6V)] ordering of the FREE vector
+ * [shared | poses] used internally; returns 0 if some pose block is not PD. */
+static int calib_build_reduced(calib_lin *L, const double *Ds, const double *Dp, double *S, double *gred) {
+    const orc_calib_problem *pb = L->pb;
+    const int nci = L->nci, ns = L->ns;
+    memcpy(S, L->U, sizeof(double) * (size_t)ns * ns);
+    for (int i = 0; i < ns; ++i) { S[(size_t)i * ns + i] += Ds[i]; gred[i] = L->gs[i]; }
+    int *cols = malloc(sizeof(int) * (nci + 3 * (size_t)pb->P + 3));
+    double *Wrow = malloc(sizeof(double) * 6 * (nci + 3 * (size_t)pb->P + 3));
+    double *Trow = malloc(sizeof(double) * 6 * (nci + 3 * (size_t)pb->P + 3));
+    int ok = 1;
+    for (int v = 0; v < pb->V && ok; ++v) {
+        int c = pb->cam_of_view[v];
+        int nobs = pb->view_off[v + 1] - pb->view_off[v];
+        int k = nci + (pb->fix_points ? 0 : 3 * nobs);
+        if (k == 0) continue;
+        /* gather this view's nonzero columns */
+        for (int b = 0; b < nci; ++b) cols[b] = c * nci + b;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < nci; ++b) Wrow[a * k + b] = L->Wc[((size_t)v * 6 + a) * nci + b];
+        if (!pb->fix_points) for (int j = 0; j < nobs; ++j) {
+            int o = pb->view_off[v] + j;
+            for (int b = 0; b < 3; ++b) {
+                cols[nci + 3 * j + b] = L->off_pt + 3 * pb->point_id[o] + b;
+                for (int a = 0; a < 6; ++a) Wrow[a * k + nci + 3 * j + b] = L->Wx[18 * (size_t)o + a * 3 + b];
+            }
+        }
+        double Lc[36];
+        memcpy(Lc, L->Vv + 36 * v, sizeof Lc);
+        for (int a = 0; a < 6; ++a) Lc[a * 6 + a] += Dp[6 * v + a];
+        if (!chol6(Lc)) { ok = 0; break; }
+        memcpy(Trow, Wrow, sizeof(double) * 6 * k);
+        for (int j = 0; j < k; ++j) chol6_solve(Lc, Trow + j, k);
+        double y[6]; memcpy(y, L->gv + 6 * v, sizeof y);
+        chol6_solve(Lc, y, 1);
+        for (int i = 0; i < k; ++i) {
+            double *Srow = S + (size_t)cols[i] * ns;
+            double w0 = Wrow[0 * k + i], w1 = Wrow[1 * k + i], w2 = Wrow[2 * k + i];
+            double w3 = Wrow[3 * k + i], w4 = Wrow[4 * k + i], w5 = Wrow[5 * k + i];
+            for (int j = 0; j < k; ++j)
+                Srow[cols[j]] -= w0 * Trow[j] + w1 * Trow[k + j] + w2 * Trow[2 * k + j] +
+                                 w3 * Trow[3 * k + j] + w4 * Trow[4 * k + j] + w5 * Trow[5 * k + j];
+            gred[cols[i]] -= w0 * y[0] + w1 * y[1] + w2 * y[2] + w3 * y[3] + w4 * y[4] + w5 * y[5];
+        }
+    }
+    free(cols); free(Wrow); free(Trow);
+    return ok;
+}
+
+/* model callbacks: global x = [intr 9C | poses 6V | points 3P]; tangent = [shared ns | poses 6V] */
+typedef struct { calib_lin L; const orc_calib_problem *pb; } calib_ctx;
+
+static double calib_m_linearize(void *vc, const double *x, double *diag, double *grad) {
+    calib_ctx *c = vc; const orc_calib_problem *pb = c->pb; calib_lin *L = &c->L;
+    calib_linearize_blocks(L, x, x + 9 * pb->C, x + 9 * pb->C + 6 * pb->V);
+    for (int i = 0; i < L->ns; ++i) { diag[i] = L->U[(size_t)i * L->ns + i]; grad[i] = L->gs[i]; }
+    for (int v = 0; v < pb->V; ++v) for (int a = 0; a < 6; ++a) {
+        diag[L->ns + 6 * v + a] = L->Vv[36 * v + a * 6 + a];
+        grad[L->ns + 6 * v + a] = L->gv[6 * v + a];
+    }
+    return L->cost;
+}
+static int calib_m_solve(void *vc, const double *D, double *delta) {
+    calib_ctx *c = vc; const orc_calib_problem *pb = c->pb; calib_lin *L = &c->L;
+    const int ns = L->ns, nci = L->nci;
+    if (!calib_build_reduced(L, D, D + ns, L->S, L->rhs)) return 0;
+    for (int i = 0; i < ns; ++i) L->rhs[i] = -L->rhs[i];
+    if (ns > 0 && !orc_cholesky_solve(ns, L->S, L->rhs)) return 0;
+    memcpy(delta, L->rhs, sizeof(double) * ns);
+    /* back-substitute poses: dp = -(V + Dp)^-1 (g + W ds) */
+    for (int v = 0; v < pb->V; ++v) {
+        int cc = pb->cam_of_view[v];
+        double b[6];
+        for (int a = 0; a < 6; ++a) {
+            double t = L->gv[6 * v + a];
+            for (int k = 0; k < nci; ++k) t += L->Wc[((size_t)v * 6 + a) * nci + k] * delta[cc * nci + k];
+            b[a] = t;
+        }
+        if (!pb->fix_points) for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            const double *Wx = L->Wx + 18 * (size_t)o;
+            const double *dx = delta + L->off_pt + 3 * pb->point_id[o];
+            for (int a = 0; a < 6; ++a) b[a] += Wx[a * 3] * dx[0] + Wx[a * 3 + 1] * dx[1] + Wx[a * 3 + 2] * dx[2];
+        }
+        double Lc[36]; memcpy(Lc, L->Vv + 36 * v, sizeof Lc);
+        for (int a = 0; a < 6; ++a) Lc[a * 6 + a] += D[ns + 6 * v + a];
+        if (!chol6(Lc)) return 0;
+        chol6_solve(Lc, b, 1);
+        for (int a = 0; a < 6; ++a) delta[ns + 6 * v + a] = -b[a];
+    }
+    return 1;
+}
+static void calib_m_plus(void *vc, const double *x, const double *delta, double *xo) {
+    calib_ctx *c = vc; const orc_calib_problem *pb = c->pb; calib_lin *L = &c->L;
+    const int ng = 9 * pb->C + 6 * pb->V + 3 * pb->P;
+    memcpy(xo, x, sizeof(double) * ng);
+    for (int cc = 0; cc < pb->C; ++cc) for (int k = 0; k < L->nci; ++k) xo[9 * cc + cam_col(pb, k)] += delta[cc * L->nci + k];
+    for (int i = 0; i < 6 * pb->V; ++i) xo[9 * pb->C + i] += delta[L->ns + i];
+    if (!pb->fix_points) for (int i = 0; i < 3 * pb->P; ++i) xo[9 * pb->C + 6 * pb->V + i] += delta[L->off_pt + i];
+}
+static double calib_m_cost(void *vc, const double *x) {
+    calib_ctx *c = vc; const orc_calib_problem *pb = c->pb;
+    return orc_calib_cost(pb, x, x + 9 * pb->C, x + 9 * pb->C + 6 * pb->V);
+}
+static double calib_m_free_norm2(void *vc, const double *x) {
+    calib_ctx *c = vc; const orc_calib_problem *pb = c->pb; calib_lin *L = &c->L;
+    double s = 0;
+    for (int cc = 0; cc < pb->C; ++cc) for (int k = 0; k < L->nci; ++k) { double a = x[9 * cc + cam_col(pb, k)]; s += a * a; }
+    for (int i = 0; i < 6 * pb->V; ++i) { double a = x[9 * pb->C + i]; s += a * a; }
+    if (!pb->fix_points) for (int i = 0; i < 3 * pb->P; ++i) { double a = x[9 * pb->C + 6 * pb->V + i]; s += a * a; }
+    return s;
+}
+
+void orc_calib_normal_blocks(const orc_calib_problem *pb, const double *intr, const double *poses,
+                             const double *points, double *Vv, double *gv, double *U, double *gs,
+                             double *W, double *cost) {
+    calib_lin L; calib_lin_alloc(&L, pb);
+    calib_linearize_blocks(&L, intr, poses, points);
+    const int ns = L.ns, nci = L.nci;
+    if (Vv) memcpy(Vv, L.Vv, sizeof(double) * 36 * pb->V);
+    if (gv) memcpy(gv, L.gv, sizeof(double) * 6 * pb->V);
+    if (U) memcpy(U, L.U, sizeof(double) * (size_t)ns * ns);
+    if (gs) memcpy(gs, L.gs, sizeof(double) * ns);
+    if (W) {
+        memset(W, 0, sizeof(double) * (size_t)pb->V * 6 * ns);
+        for (int v = 0; v < pb->V; ++v) {
+            int c = pb->cam_of_view[v];
+            for (int a = 0; a < 6; ++a) {
+                double *row = W + ((size_t)v * 6 + a) * ns;
+                for (int k = 0; k < nci; ++k) row[c * nci + k] = L.Wc[((size_t)v * 6 + a) * nci + k];
+                if (!pb->fix_points) for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o)
+                    for (int b = 0; b < 3; ++b) row[L.off_pt + 3 * pb->point_id[o] + b] += L.Wx[18 * (size_t)o + a * 3 + b];
+            }
+        }
+    }
+    if (cost) *cost = L.cost;
+    calib_lin_free(&L);
+}
+
+void orc_calib_reduced_system(const orc_calib_problem *pb, const double *intr, const double *poses,
+                              const double *points, const double *Dp, const double *Ds,
+                              double *S, double *gred, double *cost) {
+    calib_lin L; calib_lin_alloc(&L, pb);
+    calib_linearize_blocks(&L, intr, poses, points);
+    calib_build_reduced(&L, Ds, Dp, S, gred);
+    if (cost) *cost = L.cost;
+    calib_lin_free(&L);
+}
+
+int orc_calib_solve(const orc_calib_problem *pb, double *intr, double *poses, double *points,
+                    const orc_lm_options *opt, orc_lm_summary *sum) {
+    calib_ctx c; c.pb = pb; calib_lin_alloc(&c.L, pb);
+    const int ng = 9 * pb->C + 6 * pb->V + 3 * pb->P;
+    double *x = malloc(sizeof(double) * ng);
+    memcpy(x, intr, sizeof(double) * 9 * pb->C);
+    memcpy(x + 9 * pb->C, poses, sizeof(double) * 6 * pb->V);
+    memcpy(x + 9 * pb->C + 6 * pb->V, points, sizeof(double) * 3 * pb->P);
+    lm_model m = { &c, c.L.ns + 6 * pb->V, ng, calib_m_linearize, calib_m_solve, calib_m_plus, calib_m_cost, calib_m_free_norm2 };
+    int term = (opt->strategy == 1) ? lm_nielsen(&m, x, opt, sum) : lm_ceres(&m, x, opt, sum);
+    memcpy(intr, x, sizeof(double) * 9 * pb->C);
+    memcpy(poses, x + 9 * pb->C, sizeof(double) * 6 * pb->V);
+    memcpy(points, x + 9 * pb->C + 6 * pb->V, sizeof(double) * 3 * pb->P);
+    free(x); calib_lin_free(&c.L);
+    return term;
+}
+
+double orc_calib_refine_return(double total_cost, int N) { return sqrt(total_cost / (2.0 * N)); }
+
+/* ======================================================================== */
+/* hand-eye problem                                                          */
+/* ======================================================================== */
+typedef struct { const orc_handeye_problem *pb; double H[36], g[6]; } he_ctx;
+
+/* QuaternionParameterization::ComputeJacobian, 4x3 row-major */
+static void quat_plus_jac(const double x[4], double P[12]) {
+    P[0] = -x[1]; P[1] = -x[2]; P[2] = -x[3];
+    P[3] = x[0];  P[4] = x[3];  P[5] = -x[2];
+    P[6] = -x[3]; P[7] = x[0];  P[8] = x[1];
+    P[9] = x[2];  P[10] = -x[1]; P[11] = x[0];
+}
+
+double orc_handeye_cost(const orc_handeye_problem *pb, const double p[7]) {
+    double s = 0;
+    for (int i = 0; i < pb->n; ++i) {
+        double r[12];
+        orc_handeye_analytic(p, p + 4, pb->qa + 4 * i, pb->ta + 3 * i, pb->qb + 4 * i, pb->tb + 3 * i, r, 0, 0);
+        for (int k = 0; k < 12; ++k) s += r[k] * r[k];
+    }
+    return 0.5 * s;
+}
+
+void orc_handeye_normal_eq(const orc_handeye_problem *pb, const double p[7],
+                           double H[36], double g[6], double *cost) {
+    double P[12]; quat_plus_jac(p, P);
+    memset(H, 0, 36 * sizeof(double)); memset(g, 0, 6 * sizeof(double));
+    double s = 0;
+    for (int i = 0; i < pb->n; ++i) {
+        double r[12], Jq[48], Jt[36], J[72];
+        orc_handeye_analytic(p, p + 4, pb->qa + 4 * i, pb->ta + 3 * i, pb->qb + 4 * i, pb->tb + 3 * i, r, Jq, Jt);
+        for (int k = 0; k < 12; ++k) {
+            for (int a = 0; a < 3; ++a)
+                J[k * 6 + a] = Jq[k * 4 + 0] * P[0 + a] + Jq[k * 4 + 1] * P[3 + a] + Jq[k * 4 + 2] * P[6 + a] + Jq[k * 4 + 3] * P[9 + a];
+            for (int a = 0; a < 3; ++a) J[k * 6 + 3 + a] = Jt[k * 3 + a];
+            s += r[k] * r[k];
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) H[a * 6 + b] += J[k * 6 + a] * J[k * 6 + b];
+                g[a] += J[k * 6 + a] * r[k];
+            }
+        }
+    }
+    if (cost) *cost = 0.5 * s;
+}
+
+static double he_m_linearize(void *vc, const double *x, double *diag, double *grad) {
+    he_ctx *c = vc; double cost;
+    orc_handeye_normal_eq(c->pb, x, c->H, c->g, &cost);
+    for (int a = 0; a < 6; ++a) { diag[a] = c->H[a * 6 + a]; grad[a] = c->g[a]; }
+    return cost;
+}
+static int he_m_solve(void *vc, const double *D, double *delta) {
+    he_ctx *c = vc; double A[36];
+    memcpy(A, c->H, sizeof A);
+    for (int a = 0; a < 6; ++a) { A[a * 6 + a] += D[a]; delta[a] = -c->g[a]; }
+    return orc_cholesky_solve(6, A, delta);
+}
+static void he_m_plus(void *vc, const double *x, const double *delta, double *xo) {
+    (void)vc;
+    orc_quaternion_plus(x, delta, xo);
+    for (int a = 0; a < 3; ++a) xo[4 + a] = x[4 + a] + delta[3 + a];
+}
+static double he_m_cost(void *vc, const double *x) { he_ctx *c = vc; return orc_handeye_cost(c->pb, x); }
+static double he_m_free_norm2(void *vc, const double *x) { (void)vc; double s = 0; for (int i = 0; i < 7; ++i) s += x[i] * x[i]; return s; }
+
+int orc_handeye_solve(const orc_handeye_problem *pb, double p[7],
+                      const orc_lm_options *opt, orc_lm_summary *sum) {
+    he_ctx c; c.pb = pb;
+    lm_model m = { &c, 6, 7, he_m_linearize, he_m_solve, he_m_plus, he_m_cost, he_m_free_norm2 };
+    return (opt->strategy == 1) ? lm_nielsen(&m, p, opt, sum) : lm_ceres(&m, p, opt, sum);
+}
+
+/* ======================================================================== */
+/* dense levmar restatement: lm_core.c:60-423                                */
+/* ======================================================================== */
+int orc_lm_nielsen_der(orc_lm_func func, orc_lm_func jacf, double *p, const double *x,
+                       int m, int n, int itmax, const double opts[4], double info[10],
+                       void *adata) {
+    double tau = 1e-3, eps1 = 1e-17, eps2 = 1e-17, eps3 = 1e-17;   /* levmar.h:90-91 */
+    if (opts) { tau = opts[0]; eps1 = opts[1]; eps2 = opts[2]; eps3 = opts[3]; }
+    const double eps2_sq = eps2 * eps2;
+    double *e = malloc(sizeof(double) * n), *hx = malloc(sizeof(double) * n);
+    double *jac = malloc(sizeof(double) * (size_t)n * m), *JtJ = malloc(sizeof(double) * (size_t)m * m);
+    double *A = malloc(sizeof(double) * (size_t)m * m);
+    double *Jte = malloc(sizeof(double) * m), *Dp = malloc(sizeof(double) * m), *pDp = malloc(sizeof(double) * m);
+    double mu = 0, jacTe_inf = 0, p_eL2, pDp_eL2, p_L2, Dp_L2 = DBL_MAX, init_p_eL2;
+    int nu = 2, stop = 0, nfev, njev = 0, nlss = 0, k;
+
+    func(p, hx, m, n, adata); nfev = 1;
+    p_eL2 = 0;
+    for (int i = 0; i < n; ++i) { e[i] = (x ? x[i] : 0.0) - hx[i]; p_eL2 += e[i] * e[i]; }
+    init_p_eL2 = p_eL2;
+    if (!isfinite(p_eL2)) stop = 7;
+    for (k = 0; k < itmax && !stop; ++k) {
+        if (p_eL2 <= eps3) { stop = 6; break; }
+        jacf(p, jac, m, n, adata); ++njev;
+        /* J^T J (lower triangle then mirrored) and J^T e, lm_core.c:217-237 */
+        memset(JtJ, 0, sizeof(double) * (size_t)m * m); memset(Jte, 0, sizeof(double) * m);
+        for (int l = 0; l < n; ++l) {
+            const double *row = jac + (size_t)l * m;
+            for (int i = 0; i < m; ++i) {
+                double alpha = row[i];
+                if (alpha == 0.0) continue;
+                double *dst = JtJ + (size_t)i * m;
+                for (int j = 0; j <= i; ++j) dst[j] += row[j] * alpha;
+                Jte[i] += alpha * e[l];
+            }
+        }
+        for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) JtJ[(size_t)i * m + j] = JtJ[(size_t)j * m + i];
+        p_L2 = 0; jacTe_inf = 0;
+        for (int i = 0; i < m; ++i) { double a = fabs(Jte[i]); if (a > jacTe_inf) jacTe_inf = a; p_L2 += p[i] * p[i]; }
+        if (jacTe_inf <= eps1) { Dp_L2 = 0; stop = 1; break; }
+        if (k == 0) {
+            double mx = DBL_MIN; for (int i = 0; i < m; ++i) if (JtJ[(size_t)i * m + i] > mx) mx = JtJ[(size_t)i * m + i];
+            mu = tau * mx;
+        }
+        for (;;) {
+            memcpy(A, JtJ, sizeof(double) * (size_t)m * m);
+            for (int i = 0; i < m; ++i) { A[(size_t)i * m + i] += mu; Dp[i] = Jte[i]; }
+            int ok = orc_cholesky_solve(m, A, Dp); ++nlss;
+            if (ok) {
+                Dp_L2 = 0;
+                for (int i = 0; i < m; ++i) { pDp[i] = p[i] + Dp[i]; Dp_L2 += Dp[i] * Dp[i]; }
+                if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
+                if (Dp_L2 >= (p_L2 + eps2) / (DBL_EPSILON * DBL_EPSILON)) { stop = 4; break; }
+                func(pDp, hx, m, n, adata); ++nfev;
+                pDp_eL2 = 0;
+                for (int i = 0; i < n; ++i) { hx[i] = (x ? x[i] : 0.0) - hx[i]; pDp_eL2 += hx[i] * hx[i]; }
+                if (!isfinite(pDp_eL2)) { stop = 7; break; }
+                double dL = 0; for (int i = 0; i < m; ++i) dL += Dp[i] * (mu * Dp[i] + Jte[i]);
+                double dF = p_eL2 - pDp_eL2;
+                if (dL > 0.0 && dF > 0.0) {
+                    double t = 2.0 * dF / dL - 1.0; t = 1.0 - t * t * t;
+                    mu = mu * ((t >= 1.0 / 3.0) ? t : 1.0 / 3.0);
+                    nu = 2;
+                    memcpy(p, pDp, sizeof(double) * m);
+                    memcpy(e, hx, sizeof(double) * n);
+                    p_eL2 = pDp_eL2;
+                    break;
+                }
+            }
+            mu *= nu;
+            int nu2 = nu << 1;
+            if (nu2 <= nu) { stop = 5; break; }
+            nu = nu2;
+        }
+    }
+    if (k >= itmax && !stop) stop = 3;
+    if (info) {
+        info[0] = init_p_eL2; info[1] = p_eL2; info[2] = jacTe_inf; info[3] = Dp_L2;
+        double mx = DBL_MIN; for (int i = 0; i < m; ++i) if (JtJ[(size_t)i * m + i] > mx) mx = JtJ[(size_t)i * m + i];
+        info[4] = mu / mx; info[5] = k; info[6] = stop; info[7] = nfev; info[8] = njev; info[9] = nlss;
+    }
+    free(e); free(hx); free(jac); free(JtJ); free(A); free(Jte); free(Dp); free(pDp);
+    return (stop != 4 && stop != 7) ? k : -1;
+}

@@ -1,0 +1,235 @@
+"""ctypes bindings for oracle/libcvx_oracle.so (and oracle/_ref/liblevmar_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under cvx_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+TRACE_MAX = 1024
+
+
+class CalibProblem(C.Structure):
+    _fields_ = [("C", C.c_int), ("V", C.c_int), ("P", C.c_int), ("N", C.c_int),
+                ("cam_of_view", c_int_p), ("view_off", c_int_p), ("point_id", c_int_p),
+                ("obs_x", c_double_p), ("obs_y", c_double_p),
+                ("fix_k3", C.c_int), ("fix_intrinsics", C.c_int), ("fix_points", C.c_int)]
+
+
+class LMOptions(C.Structure):
+    _fields_ = [("strategy", C.c_int), ("max_iterations", C.c_int),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double),
+                ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("jacobi_scaling", C.c_int), ("nonmonotonic", C.c_int),
+                ("max_consecutive_nonmonotonic_steps", C.c_int),
+                ("tau", C.c_double), ("eps1", C.c_double), ("eps2", C.c_double), ("eps3", C.c_double)]
+
+
+class LMSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("num_successful", C.c_int), ("num_linear_solves", C.c_int),
+                ("termination", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("trace_len", C.c_int),
+                ("trace_cost", C.c_double * TRACE_MAX), ("trace_accepted", C.c_double * TRACE_MAX),
+                ("trace_damping", C.c_double * TRACE_MAX), ("trace_gradient", C.c_double * TRACE_MAX)]
+
+    def trace(self):
+        n = self.trace_len
+        return {"cost": np.array(self.trace_cost[:n]), "accepted": np.array(self.trace_accepted[:n]),
+                "damping": np.array(self.trace_damping[:n]), "gradient": np.array(self.trace_gradient[:n])}
+
+
+class HandEyeProblem(C.Structure):
+    _fields_ = [("n", C.c_int), ("qa", c_double_p), ("ta", c_double_p), ("qb", c_double_p), ("tb", c_double_p)]
+
+
+LM_FUNC = C.CFUNCTYPE(None, c_double_p, c_double_p, C.c_int, C.c_int, C.c_void_p)
+
+
+def build(force=False):
+    """Compile the C restatement (and, when /root/reference exists, levmar into oracle/_ref)."""
+    so = os.path.join(_HERE, "libcvx_oracle.so")
+    src = os.path.join(_HERE, "cvx_oracle.c")
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    ref_missing = os.path.isdir("/root/reference") and not os.path.exists(os.path.join(_HERE, "_ref", "liblevmar_ref.so"))
+    if force or stale or ref_missing:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libcvx_oracle.so"))
+        dp, ip = c_double_p, c_int_p
+        L.orc_reproj_analytic.argtypes = [dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]
+        L.orc_reproj_autodiff.argtypes = L.orc_reproj_analytic.argtypes
+        L.orc_handeye_analytic.argtypes = [dp] * 9
+        L.orc_handeye_autodiff.argtypes = [dp] * 9
+        L.orc_angle_axis_to_rotation.argtypes = [dp, dp]
+        L.orc_rotation_to_angle_axis.argtypes = [dp, dp]
+        L.orc_quaternion_plus.argtypes = [dp, dp, dp]
+        for f in (L.orc_lm_options_refine, L.orc_lm_options_handeye, L.orc_lm_options_levmar):
+            f.argtypes = [C.POINTER(LMOptions)]
+        pp = C.POINTER(CalibProblem)
+        L.orc_calib_num_shared.argtypes = [pp]; L.orc_calib_num_shared.restype = C.c_int
+        L.orc_calib_num_free.argtypes = [pp]; L.orc_calib_num_free.restype = C.c_int
+        L.orc_calib_cost.argtypes = [pp, dp, dp, dp]; L.orc_calib_cost.restype = C.c_double
+        L.orc_calib_eval.argtypes = [pp, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_calib_dense_jacobian.argtypes = [pp, dp, dp, dp, dp]
+        L.orc_calib_normal_blocks.argtypes = [pp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_calib_reduced_system.argtypes = [pp, dp, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_calib_solve.argtypes = [pp, dp, dp, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]
+        L.orc_calib_solve.restype = C.c_int
+        L.orc_calib_refine_return.argtypes = [C.c_double, C.c_int]; L.orc_calib_refine_return.restype = C.c_double
+        hp = C.POINTER(HandEyeProblem)
+        L.orc_handeye_cost.argtypes = [hp, dp]; L.orc_handeye_cost.restype = C.c_double
+        L.orc_handeye_normal_eq.argtypes = [hp, dp, dp, dp, dp]
+        L.orc_handeye_solve.argtypes = [hp, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]
+        L.orc_handeye_solve.restype = C.c_int
+        L.orc_lm_nielsen_der.argtypes = [LM_FUNC, LM_FUNC, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_void_p]
+        L.orc_lm_nielsen_der.restype = C.c_int
+        L.orc_cholesky_solve.argtypes = [C.c_int, dp, dp]; L.orc_cholesky_solve.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def levmar_ref():
+    """The reference's own levmar 2.5 (built from /root/reference by oracle/Makefile), or None."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "liblevmar_ref.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.dlevmar_der.argtypes = [LM_FUNC, LM_FUNC, c_double_p, c_double_p, C.c_int, C.c_int, C.c_int,
+                                  c_double_p, c_double_p, c_double_p, c_double_p, C.c_void_p]
+        R.dlevmar_der.restype = C.c_int
+        _REF = R
+    return _REF
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Calib:
+    """Oracle view of one calibration problem (numpy in / numpy out)."""
+
+    def __init__(self, cam_of_view, view_off, point_id, obs_x, obs_y, n_cameras, n_points,
+                 fix_k3=True, fix_intrinsics=False, fix_points=False):
+        self.cam_of_view = i32(cam_of_view); self.view_off = i32(view_off); self.point_id = i32(point_id)
+        self.obs_x = f64(obs_x); self.obs_y = f64(obs_y)
+        self.C, self.P = int(n_cameras), int(n_points)
+        self.V, self.N = len(self.cam_of_view), len(self.point_id)
+        self.pb = CalibProblem(self.C, self.V, self.P, self.N, _ip(self.cam_of_view), _ip(self.view_off),
+                               _ip(self.point_id), _dp(self.obs_x), _dp(self.obs_y),
+                               int(fix_k3), int(fix_intrinsics), int(fix_points))
+        self.ns = lib().orc_calib_num_shared(C.byref(self.pb))
+        self.nfree = lib().orc_calib_num_free(C.byref(self.pb))
+
+    def cost(self, intr, poses, points):
+        intr, poses, points = f64(intr), f64(poses), f64(points)
+        return lib().orc_calib_cost(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points))
+
+    def eval(self, intr, poses, points):
+        intr, poses, points = f64(intr), f64(poses), f64(points)
+        r = np.zeros(2 * self.N); Jc = np.zeros((self.N, 2, 9)); Jp = np.zeros((self.N, 2, 6)); Jx = np.zeros((self.N, 2, 3))
+        lib().orc_calib_eval(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points), _dp(r), _dp(Jc), _dp(Jp), _dp(Jx))
+        return r.reshape(self.N, 2), Jc, Jp, Jx
+
+    def dense_jacobian(self, intr, poses, points):
+        intr, poses, points = f64(intr), f64(poses), f64(points)
+        J = np.zeros((2 * self.N, self.nfree))
+        lib().orc_calib_dense_jacobian(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points), _dp(J))
+        return J
+
+    def normal_blocks(self, intr, poses, points, with_W=True):
+        intr, poses, points = f64(intr), f64(poses), f64(points)
+        Vv = np.zeros((self.V, 6, 6)); gv = np.zeros((self.V, 6))
+        U = np.zeros((self.ns, self.ns)); gs = np.zeros(self.ns)
+        W = np.zeros((self.V, 6, self.ns)) if with_W else None
+        cost = C.c_double()
+        lib().orc_calib_normal_blocks(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points), _dp(Vv), _dp(gv),
+                                      _dp(U), _dp(gs), _dp(W), C.byref(cost))
+        return Vv, gv, U, gs, W, cost.value
+
+    def reduced_system(self, intr, poses, points, Dp, Ds):
+        intr, poses, points, Dp, Ds = f64(intr), f64(poses), f64(points), f64(Dp), f64(Ds)
+        S = np.zeros((self.ns, self.ns)); g = np.zeros(self.ns); cost = C.c_double()
+        lib().orc_calib_reduced_system(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points), _dp(Dp), _dp(Ds),
+                                       _dp(S), _dp(g), C.byref(cost))
+        return S, g, cost.value
+
+    def solve(self, intr, poses, points, options):
+        intr, poses, points = f64(intr).copy(), f64(poses).copy(), f64(points).copy()
+        s = LMSummary()
+        lib().orc_calib_solve(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points), C.byref(options), C.byref(s))
+        return intr, poses, points, s
+
+
+class HandEye:
+    def __init__(self, qa, ta, qb, tb):
+        self.qa, self.ta, self.qb, self.tb = f64(qa), f64(ta), f64(qb), f64(tb)
+        self.n = len(self.qa)
+        self.pb = HandEyeProblem(self.n, _dp(self.qa), _dp(self.ta), _dp(self.qb), _dp(self.tb))
+
+    def cost(self, p):
+        p = f64(p)
+        return lib().orc_handeye_cost(C.byref(self.pb), _dp(p))
+
+    def normal_eq(self, p):
+        p = f64(p); H = np.zeros((6, 6)); g = np.zeros(6); cost = C.c_double()
+        lib().orc_handeye_normal_eq(C.byref(self.pb), _dp(p), _dp(H), _dp(g), C.byref(cost))
+        return H, g, cost.value
+
+    def solve(self, p, options):
+        p = f64(p).copy(); s = LMSummary()
+        lib().orc_handeye_solve(C.byref(self.pb), _dp(p), C.byref(options), C.byref(s))
+        return p, s
+
+
+def options(kind="refine"):
+    o = LMOptions()
+    {"refine": lib().orc_lm_options_refine, "handeye": lib().orc_lm_options_handeye,
+     "levmar": lib().orc_lm_options_levmar}[kind](C.byref(o))
+    return o
+
+
+def reproj(intr, pose, X, ox, oy, autodiff=False):
+    intr, pose, X = f64(intr), f64(pose), f64(X)
+    r = np.zeros(2); Jc = np.zeros((2, 9)); Jp = np.zeros((2, 6)); Jx = np.zeros((2, 3))
+    f = lib().orc_reproj_autodiff if autodiff else lib().orc_reproj_analytic
+    f(_dp(intr), _dp(pose), _dp(X), float(ox), float(oy), _dp(r), _dp(Jc), _dp(Jp), _dp(Jx))
+    return r, Jc, Jp, Jx
+
+
+def handeye(q, t, qa, ta, qb, tb, autodiff=False):
+    a = [f64(v) for v in (q, t, qa, ta, qb, tb)]
+    r = np.zeros(12); Jq = np.zeros((12, 4)); Jt = np.zeros((12, 3))
+    f = lib().orc_handeye_autodiff if autodiff else lib().orc_handeye_analytic
+    f(*[_dp(v) for v in a], _dp(r), _dp(Jq), _dp(Jt))
+    return r, Jq, Jt
