@@ -1,0 +1,289 @@
+// Hand-eye AX = XB refinement on MI355X: handle, HIP evaluator, C ABI.
+// Replaces the body of HandEyeCalibration::solveNonLinear between "p[7] packed" and
+// "X rebuilt" (/root/reference/modules/calib/src/handeye.cpp:282-324).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "handeye_kernels.h"
+#include "lm_driver.h"
+
+using namespace cvxh;
+
+struct cvx_handeye {
+    long long n = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_blocks = 1;
+    double *d_pairs = nullptr, *d_p7 = nullptr, *d_partial = nullptr, *d_out = nullptr;
+    double *h_out = nullptr, *h_p7 = nullptr;
+    double *d_eval = nullptr;
+    // exchange
+    cvx_allreduce_fn xfn = nullptr;
+    void *xctx = nullptr;
+    int rank = 0, nranks = 1, xdev = 0;
+    ~cvx_handeye() {
+        (void)hipSetDevice(device);
+        for (void *p : {(void *)d_pairs, (void *)d_p7, (void *)d_partial, (void *)d_out, (void *)d_eval})
+            if (p) (void)hipFree(p);
+        if (h_out) (void)hipHostFree(h_out);
+        if (h_p7) (void)hipHostFree(h_p7);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+// Ceres QuaternionParameterization::Plus (handeye.cpp:305-308)
+void quaternion_plus(const double x[4], const double d[3], double out[4]) {
+    const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n > 0.0) {
+        const double sn = std::sin(n) / n;
+        const double q[4] = {std::cos(n), sn * d[0], sn * d[1], sn * d[2]};
+        out[0] = q[0] * x[0] - q[1] * x[1] - q[2] * x[2] - q[3] * x[3];
+        out[1] = q[0] * x[1] + q[1] * x[0] + q[2] * x[3] - q[3] * x[2];
+        out[2] = q[0] * x[2] - q[1] * x[3] + q[2] * x[0] + q[3] * x[1];
+        out[3] = q[0] * x[3] + q[1] * x[2] - q[2] * x[1] + q[3] * x[0];
+    } else {
+        for (int i = 0; i < 4; ++i) out[i] = x[i];
+    }
+}
+
+void plus7(const double x[7], const double d[6], double out[7]) {
+    quaternion_plus(x, d, out);
+    for (int a = 0; a < 3; ++a) out[4 + a] = x[4 + a] + d[3 + a];
+}
+
+int upload_p(cvx_handeye *h, const double p[7]) {
+    std::memcpy(h->h_p7, p, 7 * sizeof(double));
+    CVX_HIP(hipMemcpyAsync(h->d_p7, h->h_p7, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return CVX_OK;
+}
+
+// reduce `width` doubles of the block partials, exchange, bring to h_out
+int finish(cvx_handeye *h, int width) {
+    hipLaunchKernelGGL(k_he_final, dim3(1), dim3(64), 0, h->stream, h->d_partial, h->n_blocks, width, h->d_out);
+    CVX_HIP(hipGetLastError());
+    if (h->nranks > 1 && h->xfn && h->xdev) {
+        if (h->xfn(h->xctx, h->d_out, (size_t)width, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
+    }
+    CVX_HIP(hipMemcpyAsync(h->h_out, h->d_out, width * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    if (h->nranks > 1 && h->xfn && !h->xdev) {
+        if (h->xfn(h->xctx, h->h_out, (size_t)width, 0, nullptr)) return CVX_ERR_EXCHANGE;
+    }
+    return CVX_OK;
+}
+
+int device_cost(cvx_handeye *h, const double p[7], double *cost) {
+    int st = upload_p(h, p);
+    if (st) return st;
+    hipLaunchKernelGGL(k_he_cost, dim3(h->n_blocks), dim3(256), 0, h->stream, h->d_pairs, h->n, h->d_p7, h->d_partial);
+    CVX_HIP(hipGetLastError());
+    st = finish(h, 1);
+    if (st) return st;
+    *cost = 0.5 * h->h_out[0];
+    return CVX_OK;
+}
+
+// H (6x6 row-major, symmetric), g, cost at p
+int device_normal_eq(cvx_handeye *h, const double p[7], double H[36], double g[6], double *cost) {
+    int st = upload_p(h, p);
+    if (st) return st;
+    hipLaunchKernelGGL(k_he_normal_eq, dim3(h->n_blocks), dim3(256), 0, h->stream, h->d_pairs, h->n, h->d_p7,
+                       h->d_partial);
+    CVX_HIP(hipGetLastError());
+    st = finish(h, HE_ACC);
+    if (st) return st;
+    int e = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) { H[a * 6 + b] = h->h_out[e]; H[b * 6 + a] = h->h_out[e]; ++e; }
+    for (int a = 0; a < 6; ++a) g[a] = h->h_out[21 + a];
+    *cost = 0.5 * h->h_out[27];
+    return CVX_OK;
+}
+
+class HandEyeEvaluator : public cvx::Evaluator {
+public:
+    HandEyeEvaluator(cvx_handeye *h_, double *p) : h(h_) { std::memcpy(x, p, sizeof x); }
+    cvx_handeye *h;
+    double x[7], xc[7];
+    double H[36], g[6], cost = 0;
+    double s2[6] = {1, 1, 1, 1, 1, 1};
+    bool lin_valid = false, projected = true;
+
+    void set_strategy(int strategy) override { projected = (strategy == 0); }
+
+    // Ceres: max-norm of x - Plus(x, -g); levmar: max |g|
+    double grad_norm() const {
+        double m = 0;
+        if (projected) {
+            double d[6], xo[7];
+            for (int a = 0; a < 6; ++a) d[a] = -g[a];
+            plus7(x, d, xo);
+            for (int i = 0; i < 7; ++i) m = std::max(m, std::fabs(x[i] - xo[i]));
+        } else {
+            for (int a = 0; a < 6; ++a) m = std::max(m, std::fabs(g[a]));
+        }
+        return m;
+    }
+
+    int linearize() {
+        if (lin_valid) return CVX_OK;
+        int st = device_normal_eq(h, x, H, g, &cost);
+        if (st) return st;
+        lin_valid = true;
+        return CVX_OK;
+    }
+
+    cvx::InitInfo init(bool jacobi) override {
+        cvx::InitInfo out;
+        out.status = linearize();
+        if (out.status) return out;
+        double dm = 0;
+        for (int a = 0; a < 6; ++a) {
+            if (jacobi) { const double s = 1.0 / (1.0 + std::sqrt(H[a * 6 + a])); s2[a] = s * s; }
+            else s2[a] = 1.0;
+            dm = std::max(dm, H[a * 6 + a]);
+        }
+        out.cost = cost; out.grad_max = grad_norm(); out.diag_max = dm;
+        return out;
+    }
+
+    cvx::StepInfo try_step(const cvx_damping &d, double gtol, bool gradient_only) override {
+        cvx::StepInfo out;
+        out.status = linearize();
+        if (out.status) return out;
+        out.cost = cost; out.grad_max = grad_norm();
+        if (out.grad_max <= gtol) { out.grad_converged = true; return out; }
+        if (gradient_only) return out;
+        double A[36], delta[6], D[6];
+        std::memcpy(A, H, sizeof A);
+        for (int a = 0; a < 6; ++a) {
+            double c = s2[a] * H[a * 6 + a];
+            c = std::min(std::max(c, d.min_diag), d.max_diag);
+            D[a] = c * d.inv_radius / s2[a] + d.mu;
+            A[a * 6 + a] += D[a];
+            delta[a] = -g[a];
+        }
+        bool solved = cvx::host_cholesky_solve(6, A, delta);
+        for (int a = 0; a < 6 && solved; ++a) solved = std::isfinite(delta[a]);
+        if (!solved) { out.ok = false; return out; }
+        plus7(x, delta, xc);
+        double cand = 0;
+        out.status = device_cost(h, xc, &cand);
+        if (out.status) return out;
+        double m = 0, sn = 0, xn = 0;
+        for (int a = 0; a < 6; ++a) m += delta[a] * (D[a] * delta[a] - g[a]);
+        for (int i = 0; i < 7; ++i) { sn += (x[i] - xc[i]) * (x[i] - xc[i]); xn += x[i] * x[i]; }
+        out.cand_cost = cand; out.model_change = 0.5 * m;
+        // levmar's ||Dp||^2 is over the 6 tangent coordinates, Ceres' step norm over the 7 global ones
+        double d2 = 0;
+        for (int a = 0; a < 6; ++a) d2 += delta[a] * delta[a];
+        out.step_norm2 = projected ? sn : d2;
+        out.x_norm2 = xn; out.free_norm2 = xn;
+        out.ok = std::isfinite(out.model_change);
+        return out;
+    }
+
+    int accept() override {
+        std::memcpy(x, xc, sizeof x);
+        lin_valid = false;
+        return CVX_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int cvx_handeye_create(int n_pairs, const double *qa, const double *ta, const double *qb,
+                                  const double *tb, int device, void *stream, cvx_handeye **out) {
+    if (!out) return CVX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_pairs < 0 || (n_pairs > 0 && (!qa || !ta || !qb || !tb))) return CVX_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        cvx::set_last_error("no HIP device visible");
+        return CVX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) return CVX_ERR_NO_DEVICE;
+    CVX_HIP(hipSetDevice(device));
+    cvx_handeye *h = new cvx_handeye;
+    std::unique_ptr<cvx_handeye> guard(h);
+    h->n = n_pairs; h->device = device;
+    if (stream) h->stream = (hipStream_t)stream;
+    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    h->n_blocks = (int)std::min<long long>(1024, std::max<long long>(1, (h->n + 255) / 256));
+    const size_t n = (size_t)n_pairs;
+    std::vector<double> planes(14 * std::max<size_t>(n, 1));
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k) { planes[k * n + i] = qa[4 * i + k]; planes[(7 + k) * n + i] = qb[4 * i + k]; }
+        for (int k = 0; k < 3; ++k) { planes[(4 + k) * n + i] = ta[3 * i + k]; planes[(11 + k) * n + i] = tb[3 * i + k]; }
+    }
+    CVX_HIP(hipMalloc((void **)&h->d_pairs, planes.size() * sizeof(double)));
+    CVX_HIP(hipMemcpyAsync(h->d_pairs, planes.data(), planes.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipMalloc((void **)&h->d_p7, 8 * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_partial, (size_t)h->n_blocks * HE_ACC * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_out, 32 * sizeof(double)));
+    CVX_HIP(hipHostMalloc((void **)&h->h_out, 32 * sizeof(double), hipHostMallocDefault));
+    CVX_HIP(hipHostMalloc((void **)&h->h_p7, 8 * sizeof(double), hipHostMallocDefault));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    *out = guard.release();
+    return CVX_OK;
+}
+
+extern "C" void cvx_handeye_destroy(cvx_handeye *h) { delete h; }
+
+extern "C" int cvx_handeye_cost(cvx_handeye *h, const double p[7], double *cost) {
+    if (!h || !p || !cost) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    return device_cost(h, p, cost);
+}
+
+extern "C" int cvx_handeye_normal_eq(cvx_handeye *h, const double p[7], double H[36], double g[6], double *cost) {
+    if (!h || !p || !H || !g) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    double c = 0;
+    int st = device_normal_eq(h, p, H, g, &c);
+    if (st) return st;
+    if (cost) *cost = c;
+    return CVX_OK;
+}
+
+extern "C" int cvx_handeye_evaluate(cvx_handeye *h, const double p[7], double *r, double *Jq, double *Jt) {
+    if (!h || !p) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n;
+    if (n == 0) return CVX_OK;
+    if (!h->d_eval) CVX_HIP(hipMalloc((void **)&h->d_eval, n * 96 * sizeof(double)));
+    int st = upload_p(h, p);
+    if (st) return st;
+    double *dr = h->d_eval, *dq = dr + 12 * n, *dt = dq + 48 * n;
+    hipLaunchKernelGGL(k_he_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_pairs, h->n, h->d_p7,
+                       dr, dq, dt);
+    CVX_HIP(hipGetLastError());
+    if (r) CVX_HIP(hipMemcpyAsync(r, dr, 12 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (Jq) CVX_HIP(hipMemcpyAsync(Jq, dq, 48 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (Jt) CVX_HIP(hipMemcpyAsync(Jt, dt, 36 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+extern "C" int cvx_handeye_set_exchange(cvx_handeye *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks,
+                                        int device_buffers) {
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return CVX_ERR_INVALID_ARG;
+    h->xfn = fn; h->xctx = ctx; h->rank = rank; h->nranks = nranks; h->xdev = device_buffers ? 1 : 0;
+    return CVX_OK;
+}
+
+extern "C" int cvx_handeye_solve(cvx_handeye *h, double p[7], const cvx_lm_options *opt, cvx_lm_summary *summary) {
+    if (!h || !p || !opt || !summary) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    HandEyeEvaluator ev(h, p);
+    int st = cvx::lm_minimize(ev, *opt, *summary);
+    std::memcpy(p, ev.x, 7 * sizeof(double));
+    return st;
+}

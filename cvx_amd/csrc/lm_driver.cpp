@@ -171,6 +171,7 @@ static int lm_nielsen(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summary &su
 int lm_minimize(Evaluator &ev, const cvx_lm_options &opt, cvx_lm_summary &sum) {
     std::memset(&sum, 0, sizeof sum);
     auto t0 = std::chrono::steady_clock::now();
+    ev.set_strategy(opt.strategy == 1 ? 1 : 0);
     int st = (opt.strategy == 1) ? lm_nielsen(ev, opt, sum) : lm_trust_region(ev, opt, sum);
     sum.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return st;

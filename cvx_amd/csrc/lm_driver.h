@@ -37,6 +37,8 @@ struct StepInfo {
 class Evaluator {
 public:
     virtual ~Evaluator() {}
+    // 0: Ceres-style (projected gradient norm, global step norm); 1: levmar (tangent-space norms)
+    virtual void set_strategy(int) {}
     // linearise at the current point; when jacobi_scaling, fix s_j = 1/(1+sqrt(d_j)) from it
     virtual InitInfo init(bool jacobi_scaling) = 0;
     // linearise at the current point, stop early when grad_max <= gtol (gtol < 0: never) or when

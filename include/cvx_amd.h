@@ -181,10 +181,17 @@ int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *sum
 /* value CameraCalibration::refine returns: sqrt(total_cost / (2 n_obs)), calibration.cpp:463 */
 double cvx_calib_refine_return(double total_cost, int64_t n_obs_total);
 
-/* per-phase device time (ms) of the last cvx_calib_solve / cvx_calib_linear_step, measured
- * with hipEvents on the handle's stream: [0] normal-equation kernel, [1] Schur contraction,
- * [2] assemble, [3] back-substitution, [4] candidate cost, [5] launches counted */
-int cvx_calib_phase_times(cvx_calib *h, double ms[8]);
+/* Per-phase device time, measured with hipEvents on the handle's stream while timing is enabled.
+ * ms[0..7]: accumulated milliseconds of [0] normal-equation kernel, [1] Schur contraction,
+ * [2] reduce + assemble, [3] back-substitution, [4] candidate cost; ms[8..15]: launches counted
+ * per phase.  cvx_calib_enable_timing resets the accumulators. */
+int cvx_calib_enable_timing(cvx_calib *h, int enable);
+int cvx_calib_phase_times(cvx_calib *h, double ms[16]);
+
+/* launch geometry, for stating algorithmic work: [0] Z columns, [1] reduced-system size,
+ * [2] normal-equation workgroups, [3] Schur row chunks, [4] upper-triangular tile pairs,
+ * [5] threads per normal-equation workgroup, [6] Z rows (6 * n_views) */
+int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]);
 
 /* ------------------------------------------------------------------------ */
 /* Hand-eye AX = XB refinement (HandEyeCalibration::solveNonLinear)          */
@@ -246,8 +253,9 @@ int cvx_synth_calib(const cvx_synth_calib_spec *s, int *cam_of_view, int *view_o
                     double *obs_x, double *obs_y, double *intr_gt, double *poses_gt, double *points_gt,
                     double *intr_init, double *poses_init, double *points_init);
 
-/* n_poses gripper/target pose pairs obeying AX = XB up to noise; X_gt, X_init as p[7] */
-int cvx_synth_handeye(int n_poses, uint64_t seed, double rot_noise, double trans_noise,
+/* n_poses gripper/target pose pairs obeying AX = XB up to noise, for the fixed-camera
+ * (moving = 0, solveFixed) or the moving-camera (moving = 1, solveMoving) pairing; X_gt, X_init as p[7] */
+int cvx_synth_handeye(int n_poses, uint64_t seed, double rot_noise, double trans_noise, int moving,
                       double *gripper_to_base /* n*16 */, double *target_to_sensor /* n*16 */,
                       double x_gt[7], double x_init[7]);
 
