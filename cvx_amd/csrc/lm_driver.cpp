@@ -111,6 +111,9 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
 // ---------------------------------------------------------------------------------------
 // strategy 1: levmar (Nielsen damping), lm_core.c:163-409
 // ---------------------------------------------------------------------------------------
+// constants of the reference's levmar build, levmar/lm.c:35-36
+static const double LM_EPSILON = 1E-12, LM_ONE_THIRD = 0.3333333334;
+
 static int lm_nielsen(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summary &sum) {
     InitInfo ini = ev.init(false);
     if (ini.status) return ini.status;
@@ -122,7 +125,7 @@ static int lm_nielsen(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summary &su
     if (!std::isfinite(p_eL2)) stop = 7;
     for (k = 0; k < o.max_iterations && !stop; ++k) {
         if (p_eL2 <= o.eps3) { stop = 6; break; }
-        if (k == 0) mu = o.tau * (ini.diag_max > DBL_MIN ? ini.diag_max : DBL_MIN);
+        if (k == 0) mu = o.tau * ini.diag_max;
         bool first = true;
         for (;;) {
             cvx_damping d = {0.0, mu, 0.0, 0.0};
@@ -134,7 +137,7 @@ static int lm_nielsen(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summary &su
             if (s.ok) {
                 const double Dp_L2 = s.step_norm2, p_L2 = s.free_norm2;
                 if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
-                if (Dp_L2 >= (p_L2 + o.eps2) / (DBL_EPSILON * DBL_EPSILON)) { stop = 4; break; }
+                if (Dp_L2 >= (p_L2 + o.eps2) / (LM_EPSILON * LM_EPSILON)) { stop = 4; break; }
                 const double pDp_eL2 = 2.0 * s.cand_cost;
                 if (!std::isfinite(pDp_eL2)) { stop = 7; break; }
                 const double dL = 2.0 * s.model_change;   // sum delta (mu delta - g)
@@ -143,7 +146,7 @@ static int lm_nielsen(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summary &su
                     trace_push(sum, s.cand_cost, 1, mu, s.grad_max);
                     double t = 2.0 * dF / dL - 1.0;
                     t = 1.0 - t * t * t;
-                    mu = mu * ((t >= 1.0 / 3.0) ? t : 1.0 / 3.0);
+                    mu = mu * ((t >= LM_ONE_THIRD) ? t : LM_ONE_THIRD);
                     nu = 2;
                     int st = ev.accept();
                     if (st) return st;

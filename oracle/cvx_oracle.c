@@ -13,6 +13,9 @@
 /* ======================================================================== */
 /* forward-mode dual numbers (what a ceres::Jet<double,N> carries)           */
 /* ======================================================================== */
+/* constants of the reference's levmar build, lm.c:35-36,71 */
+#define LM_EPSILON 1E-12
+#define LM_ONE_THIRD 0.3333333334
 #define ND 18
 typedef struct { double v; double d[ND]; } dual;
 
@@ -389,6 +392,63 @@ int orc_cholesky_solve(int n, double *A, double *b) {
     return 1;
 }
 
+
+/* Dense solve the no-LAPACK reference build uses inside dlevmar_der: Crout LU with implicitly scaled
+ * partial pivoting (Axb_core.c:992-1139), restated.  A (n x n row-major) and b are preserved; returns 0
+ * only when a row of A is entirely zero, exactly as the reference does (a zero pivot is replaced by
+ * machine epsilon instead of failing). */
+int orc_lu_solve(int n, const double *A, const double *b, double *x) {
+    double *lu = malloc(sizeof(double) * (size_t)n * n), *scale = malloc(sizeof(double) * n);
+    int *perm = malloc(sizeof(int) * n), ok = 1;
+    memcpy(lu, A, sizeof(double) * (size_t)n * n);
+    memcpy(x, b, sizeof(double) * n);
+    for (int r = 0; r < n && ok; ++r) {
+        double big = 0.0;
+        for (int c = 0; c < n; ++c) { double a = fabs(lu[(size_t)r * n + c]); if (a > big) big = a; }
+        if (big == 0.0) ok = 0; else scale[r] = 1.0 / big;
+    }
+    for (int c = 0; c < n && ok; ++c) {
+        int piv = -1;
+        double best = 0.0;
+        for (int r = 0; r < n; ++r) {
+            /* upper part (r < c): k < r; lower part (r >= c): k < c */
+            const int lim = r < c ? r : c;
+            double acc = lu[(size_t)r * n + c];
+            for (int k = 0; k < lim; ++k) acc -= lu[(size_t)r * n + k] * lu[(size_t)k * n + c];
+            lu[(size_t)r * n + c] = acc;
+            if (r >= c) { double t = scale[r] * fabs(acc); if (t >= best) { best = t; piv = r; } }
+        }
+        if (piv != c) {
+            for (int k = 0; k < n; ++k) { double t = lu[(size_t)piv * n + k]; lu[(size_t)piv * n + k] = lu[(size_t)c * n + k]; lu[(size_t)c * n + k] = t; }
+            scale[piv] = scale[c];
+        }
+        perm[c] = piv;
+        if (lu[(size_t)c * n + c] == 0.0) lu[(size_t)c * n + c] = DBL_EPSILON;
+        if (c != n - 1) {
+            const double inv = 1.0 / lu[(size_t)c * n + c];
+            for (int r = c + 1; r < n; ++r) lu[(size_t)r * n + c] *= inv;
+        }
+    }
+    if (ok) {
+        int first = 0;   /* 1 + index of the first nonzero of the permuted rhs (skips leading zeros) */
+        for (int r = 0; r < n; ++r) {
+            const int pr = perm[r];
+            double acc = x[pr];
+            x[pr] = x[r];
+            if (first) { for (int k = first - 1; k < r; ++k) acc -= lu[(size_t)r * n + k] * x[k]; }
+            else if (acc != 0.0) first = r + 1;
+            x[r] = acc;
+        }
+        for (int r = n - 1; r >= 0; --r) {
+            double acc = x[r];
+            for (int k = r + 1; k < n; ++k) acc -= lu[(size_t)r * n + k] * x[k];
+            x[r] = acc / lu[(size_t)r * n + r];
+        }
+    }
+    free(lu); free(scale); free(perm);
+    return ok;
+}
+
 /* ======================================================================== */
 /* LM options                                                                */
 /* ======================================================================== */
@@ -581,7 +641,7 @@ static int lm_nielsen(const lm_model *m, double *x, const orc_lm_options *o, orc
         double p_L2 = m->free_norm2(m->ctx, x);
         if (ginf <= o->eps1) { stop = 1; break; }
         if (k == 0) {
-            double mx = DBL_MIN; for (int i = 0; i < nf; ++i) if (diag[i] > mx) mx = diag[i];
+            double mx = -DBL_MAX; for (int i = 0; i < nf; ++i) if (diag[i] > mx) mx = diag[i];
             mu = o->tau * mx;
         }
         for (;;) {
@@ -591,7 +651,7 @@ static int lm_nielsen(const lm_model *m, double *x, const orc_lm_options *o, orc
             if (ok) {
                 double Dp_L2 = 0; for (int i = 0; i < nf; ++i) Dp_L2 += delta[i] * delta[i];
                 if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
-                if (Dp_L2 >= (p_L2 + o->eps2) / (DBL_EPSILON * DBL_EPSILON)) { stop = 4; break; }
+                if (Dp_L2 >= (p_L2 + o->eps2) / (LM_EPSILON * LM_EPSILON)) { stop = 4; break; }
                 m->plus(m->ctx, x, delta, xc);
                 double pDp_eL2 = 2.0 * m->cost(m->ctx, xc);
                 if (!isfinite(pDp_eL2)) { stop = 7; break; }
@@ -600,7 +660,7 @@ static int lm_nielsen(const lm_model *m, double *x, const orc_lm_options *o, orc
                 if (dL > 0.0 && dF > 0.0) {
                     trace_push(sum, 0.5 * pDp_eL2, 1, mu, ginf);
                     double t = 2.0 * dF / dL - 1.0; t = 1.0 - t * t * t;
-                    mu = mu * ((t >= 1.0 / 3.0) ? t : 1.0 / 3.0);
+                    mu = mu * ((t >= LM_ONE_THIRD) ? t : LM_ONE_THIRD);
                     nu = 2;
                     memcpy(x, xc, sizeof(double) * ng);
                     p_eL2 = pDp_eL2;
@@ -1028,6 +1088,22 @@ int orc_handeye_solve(const orc_handeye_problem *pb, double p[7],
 /* ======================================================================== */
 /* dense levmar restatement: lm_core.c:60-423                                */
 /* ======================================================================== */
+/* e = x - y (x may be NULL = 0) and ||e||^2 with the summation order of LEVMAR_L2NRMXMY
+ * (misc_core.c:712-798): four interleaved partial sums, blocks of 8 from the top down, then the tail */
+static double lm_l2_xmy(double *e, const double *x, const double *y, int n) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const int blockn = (n >> 3) << 3;
+    for (int i = blockn - 1; i >= 0; --i) {
+        e[i] = (x ? x[i] : 0.0) - y[i];
+        s[(blockn - 1 - i) & 3] += e[i] * e[i];
+    }
+    for (int i = blockn; i < n; ++i) {
+        e[i] = (x ? x[i] : 0.0) - y[i];
+        s[(7 - (n - i)) & 3] += e[i] * e[i];
+    }
+    return s[0] + s[1] + s[2] + s[3];
+}
+
 int orc_lm_nielsen_der(orc_lm_func func, orc_lm_func jacf, double *p, const double *x,
                        int m, int n, int itmax, const double opts[4], double info[10],
                        void *adata) {
@@ -1042,51 +1118,63 @@ int orc_lm_nielsen_der(orc_lm_func func, orc_lm_func jacf, double *p, const doub
     int nu = 2, stop = 0, nfev, njev = 0, nlss = 0, k;
 
     func(p, hx, m, n, adata); nfev = 1;
-    p_eL2 = 0;
-    for (int i = 0; i < n; ++i) { e[i] = (x ? x[i] : 0.0) - hx[i]; p_eL2 += e[i] * e[i]; }
+    p_eL2 = lm_l2_xmy(e, x, hx, n);
     init_p_eL2 = p_eL2;
     if (!isfinite(p_eL2)) stop = 7;
     for (k = 0; k < itmax && !stop; ++k) {
         if (p_eL2 <= eps3) { stop = 6; break; }
         jacf(p, jac, m, n, adata); ++njev;
-        /* J^T J (lower triangle then mirrored) and J^T e, lm_core.c:217-237 */
         memset(JtJ, 0, sizeof(double) * (size_t)m * m); memset(Jte, 0, sizeof(double) * m);
-        for (int l = 0; l < n; ++l) {
-            const double *row = jac + (size_t)l * m;
-            for (int i = 0; i < m; ++i) {
-                double alpha = row[i];
-                if (alpha == 0.0) continue;
-                double *dst = JtJ + (size_t)i * m;
-                for (int j = 0; j <= i; ++j) dst[j] += row[j] * alpha;
-                Jte[i] += alpha * e[l];
+        if ((long)n * m < 32 * 32) {
+            /* small problems, lm_core.c:217-237: rows visited from the last to the first */
+            for (int l = n - 1; l >= 0; --l) {
+                const double *row = jac + (size_t)l * m;
+                for (int i = 0; i < m; ++i) {
+                    const double alpha = row[i];
+                    double *dst = JtJ + (size_t)i * m;
+                    for (int j = 0; j <= i; ++j) dst[j] += row[j] * alpha;
+                    Jte[i] += alpha * e[l];
+                }
             }
+            for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) JtJ[(size_t)i * m + j] = JtJ[(size_t)j * m + i];
+        } else {
+            /* large problems, misc_core.c:80-132: every entry is a sum of 32-row partial sums */
+            for (int i = 0; i < m; ++i) for (int j = i; j < m; ++j) {
+                double tot = 0.0;
+                for (int kk = 0; kk < n; kk += 32) {
+                    const int ke = kk + 32 < n ? kk + 32 : n;
+                    double part = 0.0;
+                    for (int r = kk; r < ke; ++r) part += jac[(size_t)r * m + i] * jac[(size_t)r * m + j];
+                    tot += part;
+                }
+                JtJ[(size_t)i * m + j] = tot; JtJ[(size_t)j * m + i] = tot;
+            }
+            for (int r = 0; r < n; ++r) { const double er = e[r]; const double *row = jac + (size_t)r * m; for (int l = 0; l < m; ++l) Jte[l] += row[l] * er; }
         }
-        for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) JtJ[(size_t)i * m + j] = JtJ[(size_t)j * m + i];
         p_L2 = 0; jacTe_inf = 0;
         for (int i = 0; i < m; ++i) { double a = fabs(Jte[i]); if (a > jacTe_inf) jacTe_inf = a; p_L2 += p[i] * p[i]; }
         if (jacTe_inf <= eps1) { Dp_L2 = 0; stop = 1; break; }
         if (k == 0) {
-            double mx = DBL_MIN; for (int i = 0; i < m; ++i) if (JtJ[(size_t)i * m + i] > mx) mx = JtJ[(size_t)i * m + i];
+            double mx = -DBL_MAX; for (int i = 0; i < m; ++i) if (JtJ[(size_t)i * m + i] > mx) mx = JtJ[(size_t)i * m + i];
             mu = tau * mx;
         }
         for (;;) {
             memcpy(A, JtJ, sizeof(double) * (size_t)m * m);
-            for (int i = 0; i < m; ++i) { A[(size_t)i * m + i] += mu; Dp[i] = Jte[i]; }
-            int ok = orc_cholesky_solve(m, A, Dp); ++nlss;
+            for (int i = 0; i < m; ++i) A[(size_t)i * m + i] += mu;
+            int ok = orc_lu_solve(m, A, Jte, Dp); ++nlss;   /* AX_EQ_B_LU, lm_core.c:302 without LAPACK */
             if (ok) {
                 Dp_L2 = 0;
                 for (int i = 0; i < m; ++i) { pDp[i] = p[i] + Dp[i]; Dp_L2 += Dp[i] * Dp[i]; }
                 if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
-                if (Dp_L2 >= (p_L2 + eps2) / (DBL_EPSILON * DBL_EPSILON)) { stop = 4; break; }
+                if (Dp_L2 >= (p_L2 + eps2) / (LM_EPSILON * LM_EPSILON)) { stop = 4; break; }
                 func(pDp, hx, m, n, adata); ++nfev;
-                pDp_eL2 = 0;
-                for (int i = 0; i < n; ++i) { hx[i] = (x ? x[i] : 0.0) - hx[i]; pDp_eL2 += hx[i] * hx[i]; }
+                pDp_eL2 = lm_l2_xmy(hx, x, hx, n);
                 if (!isfinite(pDp_eL2)) { stop = 7; break; }
                 double dL = 0; for (int i = 0; i < m; ++i) dL += Dp[i] * (mu * Dp[i] + Jte[i]);
                 double dF = p_eL2 - pDp_eL2;
                 if (dL > 0.0 && dF > 0.0) {
                     double t = 2.0 * dF / dL - 1.0; t = 1.0 - t * t * t;
-                    mu = mu * ((t >= 1.0 / 3.0) ? t : 1.0 / 3.0);
+                    mu = mu * ((t >= LM_ONE_THIRD) ? t : LM_ONE_THIRD);
                     nu = 2;
                     memcpy(p, pDp, sizeof(double) * m);
                     memcpy(e, hx, sizeof(double) * n);

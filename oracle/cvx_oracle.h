@@ -162,6 +162,8 @@ int orc_lm_nielsen_der(orc_lm_func func, orc_lm_func jacf, double *p, const doub
                        int m, int n, int itmax, const double opts[4], double info[10],
                        void *adata);
 
+/* LU solve of the no-LAPACK levmar build (Axb_core.c:992-1139); A, b preserved */
+int orc_lu_solve(int n, const double *A, const double *b, double *x);
 /* dense SPD solve used by the drivers (Cholesky); returns 0 on failure */
 int orc_cholesky_solve(int n, double *A /* destroyed */, double *b /* in: rhs, out: x */);
 

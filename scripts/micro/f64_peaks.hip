@@ -1,0 +1,83 @@
+// Microbenchmarks grounding the roofline denominators used by bench.py on the box it runs on:
+//   (1) v_mfma_f64_16x16x4_f64 issue rate, (2) v_fma_f64 VALU rate, (3) HBM streaming copy.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double seed) {
+    f64x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = f64x4{0, 0, 0, 0};
+    double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_fma(double *out, int iters, double seed) {
+    double x[8];
+    for (int i = 0; i < 8; ++i) x[i] = seed + i + threadIdx.x * 1e-6;
+    const double m = 1.0000001, c = 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = __builtin_fma(x[i], m, c);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += x[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_copy(const double2 *__restrict__ in, double2 *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) k_write(double2 *__restrict__ out, size_t n, double v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = double2{v, v};
+}
+
+template <class F>
+float time_ms(F f, int reps) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f();
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) f();
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / reps;
+}
+
+int main() {
+    double *out; CK(hipMalloc(&out, 2048 * 256 * sizeof(double)));
+    const int iters = 4000;
+    for (int wps = 1; wps <= 2; ++wps) {   // waves per SIMD
+        int blocks = 256 * wps;            // 4 waves per block -> one per SIMD per block
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<4>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, 5);
+        double flops = (double)blocks * 4 * iters * 4 * 2048.0;
+        printf("mfma_f64_16x16x4 x4acc  %d wave/SIMD: %.3f ms  %.2f TFLOP/s\n", wps, ms, flops / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<9>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, 5);
+        flops = (double)blocks * 4 * iters * 9 * 2048.0;
+        printf("mfma_f64_16x16x4 x9acc  %d wave/SIMD: %.3f ms  %.2f TFLOP/s\n", wps, ms, flops / ms / 1e9);
+    }
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        int blocks = 256 * wps;
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(256), 0, 0, out, iters * 4, 1.0); }, 5);
+        double flops = (double)blocks * 256 * iters * 4 * 8 * 2.0;
+        printf("v_fma_f64  %d wave/SIMD: %.3f ms  %.2f TFLOP/s\n", wps, ms, flops / ms / 1e9);
+    }
+    size_t n = (size_t)1 << 26;   // 64 Mi double2 = 1 GiB
+    double2 *a, *b; CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16));
+    CK(hipMemset(a, 0, n * 16));
+    float ms = time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, a, b, n); }, 10);
+    printf("copy 1 GiB -> 1 GiB: %.3f ms  %.2f TB/s (read+write)\n", ms, 2.0 * n * 16 / ms / 1e9);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_write, dim3(2048), dim3(256), 0, 0, b, n, 1.0); }, 10);
+    printf("write 1 GiB: %.3f ms  %.2f TB/s\n", ms, 1.0 * n * 16 / ms / 1e9);
+    return 0;
+}

@@ -1,0 +1,152 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cvx_amd.h declares, host-side logic
+(conversions, pair construction, partitioning, synthetic workloads, option presets), and loud failure
+without a device.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cvx_amd
+from cvx_amd import capi
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cvx_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(capi.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), "libcvx_amd.so does not export %s" % n
+    # and the ctypes table covers exactly the header
+    assert sorted(capi.SIGNATURES) == names
+
+
+def test_product_does_not_touch_the_oracle():
+    # the product path may not include, link or load anything under oracle/
+    import subprocess
+    for root, _, files in os.walk(os.path.join(ROOT, "cvx_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", "Makefile")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "oracle" not in txt.lower() or f == "capi.py" and False, os.path.join(root, f)
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_status_strings_and_option_presets():
+    L = capi.lib()
+    assert L.cvx_status_string(0) == b"ok"
+    assert b"device" in L.cvx_status_string(capi.ERR_NO_DEVICE)
+    o = capi.options("refine")      # calibration.cpp:420-428
+    assert (o.strategy, o.max_iterations, o.nonmonotonic) == (0, 100, 1)
+    assert o.function_tolerance == 1e-10 and o.gradient_tolerance == 1e-10 and o.parameter_tolerance == 1e-8
+    assert o.initial_radius == 1e4 and o.min_lm_diagonal == 1e-6 and o.max_lm_diagonal == 1e32 and o.jacobi_scaling == 1
+    o = capi.options("handeye")     # handeye.cpp:310-319
+    assert (o.strategy, o.max_iterations, o.nonmonotonic) == (0, 100, 0) and o.function_tolerance == 1e-6
+    o = capi.options("levmar")      # lm.hpp:43-50,61
+    assert o.strategy == 1 and o.tau == 1e-3 and o.eps1 == o.eps2 == o.eps3 == np.finfo(float).eps
+
+
+def test_options_match_the_oracle_presets(orc):
+    for kind in ("refine", "handeye", "levmar"):
+        a, b = capi.options(kind), orc.options(kind)
+        for name, _ in orc.LMOptions._fields_:
+            assert getattr(a, name) == getattr(b, name), (kind, name)
+
+
+def test_no_device_is_a_loud_error():
+    if capi.lib().cvx_device_count() > 0:
+        pytest.skip("a device is present")
+    d = cvx_amd.synth_calib(1, 2, 3, 3, 1)
+    with pytest.raises(capi.CvxError) as e:
+        cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 1, 9)
+    assert e.value.status == capi.ERR_NO_DEVICE
+    with pytest.raises(capi.CvxError):
+        cvx_amd.HandEye(np.ones((2, 4)), np.ones((2, 3)), np.ones((2, 4)), np.ones((2, 3)))
+
+
+def test_rotation_conversions_round_trip_and_match_oracle(orc):
+    L = capi.lib()
+    rng = np.random.default_rng(0)
+    for k in range(200):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = [0.0, 1e-9, 1e-4, 3.1][k] if k < 4 else rng.uniform(0, np.pi)
+        w = ax * ang
+        R = np.zeros(9); Ro = np.zeros(9); w2 = np.zeros(3); wo = np.zeros(3)
+        L.cvx_angle_axis_to_rotation(capi.pd(w), capi.pd(R))
+        orc.lib().orc_angle_axis_to_rotation(capi.pd(w), capi.pd(Ro))
+        assert np.array_equal(R, Ro)
+        Rm = R.reshape(3, 3).T   # column-major storage
+        assert np.allclose(Rm @ Rm.T, np.eye(3), atol=1e-14 if ang > 1e-6 else 1e-8)
+        L.cvx_rotation_to_angle_axis(capi.pd(R), capi.pd(w2))
+        orc.lib().orc_rotation_to_angle_axis(capi.pd(R), capi.pd(wo))
+        assert np.allclose(w2, wo, atol=1e-15)
+        if ang > 1e-6:
+            assert np.allclose(w2, w, atol=1e-9)
+        q = np.zeros(4)
+        L.cvx_rotation_to_quaternion(capi.pd(R), capi.pd(q))
+        assert abs(np.linalg.norm(q) - 1) < 1e-12
+        T = np.zeros(16); p = np.concatenate([q, [1.0, 2.0, 3.0]])
+        L.cvx_quat_trans_to_affine(capi.pd(p), capi.pd(T))
+        assert np.allclose(T.reshape(4, 4).T[:3, :3], Rm, atol=1e-12)
+        assert np.allclose(T.reshape(4, 4).T[:3, 3], [1, 2, 3])
+
+
+def test_synthetic_calibration_workload_is_deterministic_and_float32_representable():
+    a = cvx_amd.synth_calib(2, 5, 12, 9, 20260003)
+    b = cvx_amd.synth_calib(2, 5, 12, 9, 20260003)
+    for k in ("obs_x", "obs_y", "poses_init", "intr_init", "point_id", "view_off"):
+        assert np.array_equal(a[k], b[k])
+    assert a["N"] == 2 * 5 * 108 and a["view_off"][-1] == a["N"]
+    # observations and board points come from cv::Point2f / Point3f (pattern.hpp:18-24, 40)
+    assert np.array_equal(a["obs_x"], a["obs_x"].astype(np.float32).astype(np.float64))
+    assert np.array_equal(a["points_gt"], a["points_gt"].astype(np.float32).astype(np.float64))
+    # OCVCalibrationPattern layout, pattern.hpp:53-55
+    assert np.allclose(a["points_gt"][13], [25.0, 25.0, 0.0])
+    r = cvx_amd.synth_calib(2, 5, 12, 9, 20260003, ragged=3)
+    assert 8 * 10 <= r["N"] < a["N"]
+    n_per_view = np.diff(r["view_off"])
+    assert n_per_view.min() >= 8 and len(set(n_per_view.tolist())) > 1
+    assert np.array_equal(r["poses_gt"], a["poses_gt"])
+
+
+def test_motion_pairs_obey_ax_xb_without_noise():
+    for moving in (False, True):
+        G, T, xg, x0 = cvx_amd.synth_handeye(30, 5, rot_noise=0.0, trans_noise=0.0, moving=moving)
+        A, B = cvx_amd.handeye_pairs(G, T, moving=moving)
+        if moving:
+            assert len(A) == 29                      # consecutive pairs of the sorted stations, handeye.cpp:742-746
+        else:
+            assert 0 < len(A) <= 30 * 29 // 2        # all i<j beyond 10 degrees, handeye.cpp:681-693
+        X = np.zeros(16)
+        capi.lib().cvx_quat_trans_to_affine(capi.pd(xg), capi.pd(X))
+        X = X.reshape(4, 4).T
+        for a, b in zip(A[:50], B[:50]):
+            a = a.reshape(4, 4).T; b = b.reshape(4, 4).T
+            assert np.allclose(a @ X, X @ b, atol=1e-9)
+
+
+def test_partition_views_balances_observations():
+    d = cvx_amd.synth_calib(3, 40, 12, 9, 7, ragged=3)
+    for nr in (1, 2, 3, 8):
+        first = cvx_amd.partition_views(d["view_off"], nr)
+        assert first[0] == 0 and first[-1] == d["V"] and np.all(np.diff(first) >= 0)
+        counts = [d["view_off"][first[r + 1]] - d["view_off"][first[r]] for r in range(nr)]
+        assert sum(counts) == d["N"]
+        assert max(counts) - min(counts) <= 2 * 108
+    # more ranks than views: empty shards are legal
+    first = cvx_amd.partition_views(np.array([0, 5, 9], dtype=np.int32), 4)
+    assert first[0] == 0 and first[-1] == 2 and np.all(np.diff(first) >= 0)
+
+
+def test_refine_return_value():
+    # sqrt(total_cost / (2 N)), calibration.cpp:463
+    assert capi.lib().cvx_calib_refine_return(8.0, 4) == 1.0

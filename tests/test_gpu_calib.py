@@ -1,0 +1,275 @@
+"""GPU parity tests of the calibration LM inner loop, through the C ABI (libcvx_amd.so), against the
+oracle on the same seeded inputs.  fp64 throughout; tolerances are stated next to each assertion
+(north_star: per-iteration residuals 1e-12 relative, final RMS / intrinsics / extrinsics 1e-9 relative)."""
+import numpy as np
+import pytest
+
+import cvx_amd
+from cvx_amd import capi
+from conftest import load_golden
+from test_helpers import calib_from_fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # BASELINE config 1: single camera, 20 views of a 9x6 board
+    "config1": dict(spec=(1, 20, 9, 6, 20260001), ragged=0, fix={}),
+    "config1_fixed_points": dict(spec=(1, 20, 9, 6, 20260001), ragged=0, fix={"fix_points": True}),
+    "two_cameras_ragged": dict(spec=(2, 7, 12, 9, 11), ragged=4, fix={}),
+    "three_cameras_free_k3_big_board": dict(spec=(3, 5, 20, 15, 12), ragged=3, fix={"fix_k3": False}),
+    "fixed_intrinsics": dict(spec=(1, 6, 9, 6, 13), ragged=0, fix={"fix_intrinsics": True}),
+    "all_shared_fixed": dict(spec=(2, 4, 9, 6, 14), ragged=2, fix={"fix_intrinsics": True, "fix_points": True}),
+    # a single planar view cannot determine the intrinsics (the run is chaotic): pose-only problem
+    "one_view_64_markers_exact_wave": dict(spec=(1, 1, 8, 8, 15), ragged=0, fix={"fix_points": True, "fix_intrinsics": True}),
+}
+
+
+def make(case, orc):
+    c = CASES[case]
+    C_, VP, bw, bh, seed = c["spec"]
+    d = cvx_amd.synth_calib(C_, VP, bw, bh, seed, ragged=c["ragged"])
+    args = (d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], C_, bw * bh)
+    return d, cvx_amd.Calib(*args, **c["fix"]), orc.Calib(*args, **c["fix"])
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_residuals_and_jacobians_match_oracle(orc, case):
+    d, g, o = make(case, orc)
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    cost, r, Jc, Jp, Jx = g.evaluate()
+    ro, Jco, Jpo, Jxo = o.eval(d["intr_init"], d["poses_init"], d["points_init"])
+    co = o.cost(d["intr_init"], d["poses_init"], d["points_init"])
+    assert rel_err(r, ro) < 1e-12            # residuals at identical parameters
+    for a, b in ((Jc, Jco), (Jp, Jpo), (Jx, Jxo)):
+        assert rel_err(a, b) < 1e-12
+    assert abs(cost - co) <= 1e-13 * co
+    assert abs(g.cost() - co) <= 1e-13 * co  # the cost-only kernel (Problem::Evaluate, calibration.cpp:438-442)
+    g.close()
+
+
+def test_functor_against_50_digit_fixture():
+    """r and the 2x(9|6|3) Jacobian blocks from the HIP evaluation kernel vs the mpmath values, including the
+    theta -> 0 branch of AngleAxisRotatePoint (poses 0 and 1) and a camera with k3 != 0."""
+    f = calib_from_fixture(load_golden("functor_mp.json")["calib"])
+    g = cvx_amd.Calib(f["cam_of_view"], f["view_off"], f["point_id"], f["obs_x"], f["obs_y"], f["C"], f["P"], fix_k3=False)
+    g.set_params(f["intr"], f["poses"], f["points"])
+    _, r, Jc, Jp, Jx = g.evaluate()
+    assert np.all(np.abs(r - f["r"]) <= 2e-9)     # pixels; |r| up to ~1e3, i.e. 2e-12 relative
+    for got, exp in ((Jc, f["Jc"]), (Jp, f["Jp"]), (Jx, f["Jx"])):
+        J = np.concatenate([f["Jc"], f["Jp"], f["Jx"]], axis=2)
+        scale = np.maximum(np.abs(exp), np.max(np.abs(J), axis=2, keepdims=True) * 1e-3)
+        assert np.all(np.abs(got - exp) <= 5e-12 * scale)
+    g.close()
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_damped_linear_step_matches_oracle(orc, case):
+    """One LM linear solve: Jacobi scaling, Ceres damping, Schur complement S, reduced gradient, step, model
+    change and candidate cost."""
+    d, g, o = make(case, orc)
+    x = (d["intr_init"], d["poses_init"], d["points_init"])
+    g.set_params(*x)
+    g.init_scaling(True)
+    Vv, gv, U, gs, _, cost = o.normal_blocks(*x, with_W=False)
+    radius, lo, hi = 1e4, 1e-6, 1e32
+    dU = np.diag(U) if o.ns else np.zeros(0)
+    s2s = 1.0 / (1.0 + np.sqrt(dU)) ** 2
+    Ds = np.clip(s2s * dU, lo, hi) / (s2s * radius)
+    dV = np.einsum("vii->vi", Vv).reshape(-1)
+    s2p = 1.0 / (1.0 + np.sqrt(dV)) ** 2
+    Dp = np.clip(s2p * dV, lo, hi) / (s2p * radius)
+    S, gred, _ = o.reduced_system(*x, Dp, Ds)
+    st = g.linear_step(1.0 / radius, 0.0, lo, hi)
+    assert abs(st["cost"] - cost) <= 1e-13 * cost
+    if o.ns:
+        assert rel_err(st["S"], S) < 1e-12
+        assert rel_err(st["gred"], gred) < 1e-10     # cancellation: gred = gs - W^T V^-1 gv
+        ds = np.linalg.solve(S, -gred)
+        # cond(S) is 1e8..1e10 (gauge freedom): the step agrees to cond * eps
+        assert rel_err(st["delta_shared"], ds) < 1e-7
+    else:
+        ds = np.zeros(0)
+    # back-substituted pose steps and candidate: recompute from the GPU's own shared step with the oracle
+    intr = d["intr_init"].copy(); pts = d["points_init"].copy()
+    k = 0
+    if not CASES[case]["fix"].get("fix_intrinsics"):
+        cols = [0, 1, 2, 3, 4, 5, 6, 7, 8] if CASES[case]["fix"].get("fix_k3") is False else [0, 1, 2, 3, 4, 5, 7, 8]
+        for c in range(d["C"]):
+            intr[c, cols] += st["delta_shared"][k:k + len(cols)]; k += len(cols)
+    if not CASES[case]["fix"].get("fix_points"):
+        pts += st["delta_shared"][k:].reshape(-1, 3)
+    poses = d["poses_init"] + st["delta_poses"]
+    cand = o.cost(intr, poses, pts)
+    assert abs(st["cand_cost"] - cand) <= 1e-12 * max(cand, 1.0)
+    # model change 1/2 delta^T (D delta - g) with the full gradient
+    gfull = np.concatenate([gs, gv.reshape(-1)])
+    delta = np.concatenate([st["delta_shared"], st["delta_poses"].reshape(-1)])
+    D = np.concatenate([Ds, Dp])
+    mc = 0.5 * delta @ (D * delta - gfull)
+    assert abs(st["model_change"] - mc) <= 1e-9 * abs(mc)
+    g.close()
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("kind", ["refine", "levmar"])
+def test_full_solve_follows_oracle(orc, case, kind):
+    d, g, o = make(case, orc)
+    x = (d["intr_init"], d["poses_init"], d["points_init"])
+    g.set_params(*x)
+    s = g.solve(capi.options(kind))
+    io, po, xo, so = o.solve(*x, orc.options(kind))
+    ig, pg, xg = g.get_params()
+    assert abs(s.initial_cost - so.initial_cost) <= 1e-13 * so.initial_cost
+    # per-iteration (candidate) costs.  Measured agreement is <= 3e-12 on every iteration of every case;
+    # the first steps (far from the optimum, well conditioned) are held to the 1e-12 north-star figure
+    tg, to = s.trace()["cost"], so.trace()["cost"]
+    n = min(len(tg), len(to))
+    assert n >= min(5, len(to))
+    assert np.all(np.abs(tg[1:6] - to[1:6]) <= 1e-12 * to[1:6])
+    # later iterations: the Ceres-style run (the reference's path) within 1e-10; Nielsen damping lets mu fall to
+    # ~1e-9 of the diagonal, so nearly singular pose blocks of sparse views amplify rounding up to ~1e-9
+    # (levmar's mu I damping ignores the mm / radian scale difference of the pose block and zigzags for the whole
+    # 100 iterations on the pose-only cases: rounding differences grow along the way, so the first 30 are held)
+    if kind == "refine":
+        assert np.all(np.abs(tg[:n] - to[:n]) <= 1e-10 * to[:n])
+    else:
+        m30 = min(n, 30)
+        assert np.all(np.abs(tg[:m30] - to[:m30]) <= 1e-8 * to[:m30])
+    # accept/reject decisions agree until the run has converged to rounding level (there dF > 0 is a coin toss)
+    live = np.nonzero(np.abs(to[:n] - so.final_cost) > 1e-9 * so.final_cost)[0]
+    m = (live[-1] + 1) if len(live) else 0
+    if kind != "refine":
+        m = min(m, 30)
+    assert np.array_equal(s.trace()["accepted"][:m], so.trace()["accepted"][:m])
+    if kind == "refine":
+        # Ceres-style run (the reference's own path): same iteration count and termination
+        assert (s.iterations, s.termination) == (so.iterations, so.termination)
+        assert abs(s.final_cost - so.final_cost) <= 1e-12 * so.final_cost
+        N = d["N"]
+        rg = capi.lib().cvx_calib_refine_return(s.final_cost, N)
+        assert abs(rg - orc.lib().orc_calib_refine_return(so.final_cost, N)) <= 1e-12 * rg   # RMS, 1e-9 asked
+        assert rel_err(ig, io) < 1e-9 and rel_err(pg, po) < 1e-9 and rel_err(xg, xo) < 1e-9
+    else:
+        # levmar's machine-epsilon tolerances let the two runs stop a few (flat) iterations apart
+        assert s.termination == so.termination
+        assert abs(s.final_cost - so.final_cost) <= (1e-10 if s.termination != 3 else 1e-5) * so.final_cost
+    g.close()
+
+
+def test_golden_levmar_trace_on_config1(orc):
+    """The HIP path with Nielsen damping follows the REFERENCE levmar run recorded in
+    tests/golden/levmar_calib_trace.json (dense, LU) on BASELINE config 1."""
+    gold = load_golden("levmar_calib_trace.json")
+    d = cvx_amd.synth_calib(**gold["spec"])
+    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    s = g.solve(capi.options("levmar"))
+    ref = 0.5 * np.array(gold["evals"])
+    assert abs(s.initial_cost - ref[0]) <= 1e-12 * ref[0]
+    tr = s.trace()["cost"]
+    assert np.all(np.abs(tr[:10] - ref[1:11]) <= 1e-6 * ref[1:11])
+    assert abs(s.final_cost - 0.5 * gold["info"][1]) <= 1e-9 * s.final_cost
+    intr = g.get_params()[0]
+    assert np.allclose(intr[0, [0, 1, 2, 3, 4, 5, 7, 8]], gold["p"][:8], rtol=2e-4)
+    g.close()
+
+
+def test_edge_cases():
+    # empty problem: no views at all
+    g = cvx_amd.Calib(np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0), np.zeros(0), 1, 4)
+    g.set_params(np.array([[1000, 1000, 640, 480, 0, 0, 0, 0, 0.0]]), np.zeros((0, 6)), np.zeros((4, 3)))
+    assert g.cost() == 0.0
+    g.close()
+    # a view with no markers between two populated views, and a view with a single marker
+    d = cvx_amd.synth_calib(1, 4, 5, 4, 3)
+    keep = np.ones(d["N"], bool)
+    keep[20:40] = False          # view 1 empty
+    keep[41:60] = False          # view 2 keeps one marker
+    off = np.concatenate([[0], np.cumsum([np.sum(keep[20 * v:20 * v + 20]) for v in range(4)])]).astype(np.int32)
+    args = (d["cam_of_view"], off, d["point_id"][keep], d["obs_x"][keep], d["obs_y"][keep], 1, 20)
+    from oracle import oracle as orc
+    g = cvx_amd.Calib(*args); o = orc.Calib(*args)
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    co = o.cost(d["intr_init"], d["poses_init"], d["points_init"])
+    assert abs(g.cost() - co) <= 1e-13 * co
+    _, r, Jc, Jp, Jx = g.evaluate()
+    ro, Jco, Jpo, Jxo = o.eval(d["intr_init"], d["poses_init"], d["points_init"])
+    assert rel_err(r, ro) < 1e-12 and rel_err(Jp, Jpo) < 1e-12
+    # the empty and one-marker views have singular pose blocks: only the LM damping keeps them solvable.
+    # One damped linear solve (all blocks free) against the oracle's reduced system ...
+    g.init_scaling(False)
+    Vv, gv, U, gs, _, cost = o.normal_blocks(d["intr_init"], d["poses_init"], d["points_init"], with_W=False)
+    mu = 1e-3 * max(np.max(np.diag(U)), np.max(np.einsum("vii->vi", Vv)))
+    S, gred, _ = o.reduced_system(d["intr_init"], d["poses_init"], d["points_init"], np.full(24, mu), np.full(o.ns, mu))
+    st = g.linear_step(0.0, mu, 0.0, 0.0)
+    assert rel_err(st["S"], S) < 1e-12 and rel_err(st["gred"], gred) < 1e-10
+    assert np.all(st["delta_poses"][1] == 0.0)            # nothing observes view 1: its pose does not move
+    g.close()
+    # ... and the whole solve on the well-posed variant (shared blocks fixed: pose-only)
+    fix = {"fix_intrinsics": True, "fix_points": True}
+    g = cvx_amd.Calib(*args, **fix); o = orc.Calib(*args, **fix)
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    s = g.solve(capi.options("refine"))
+    io, po, xo, so = o.solve(d["intr_init"], d["poses_init"], d["points_init"], orc.options("refine"))
+    assert s.termination == so.termination
+    assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.array_equal(g.get_params()[1][1], d["poses_init"][1])
+    g.close()
+    # invalid inputs are rejected, not run
+    with pytest.raises(capi.CvxError) as e:
+        pid = d["point_id"].copy(); pid[1] = pid[0]
+        cvx_amd.Calib(d["cam_of_view"], d["view_off"], pid, d["obs_x"], d["obs_y"], 1, 20)
+    assert e.value.status == capi.ERR_DUPLICATE_MARKER
+    with pytest.raises(capi.CvxError) as e:
+        pid = d["point_id"].copy(); pid[3] = 20
+        cvx_amd.Calib(d["cam_of_view"], d["view_off"], pid, d["obs_x"], d["obs_y"], 1, 20)
+    assert e.value.status == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.CvxError) as e:
+        cvx_amd.Calib(np.zeros(1, np.int32), np.array([0, 1], np.int32), np.zeros(1, np.int32), np.zeros(1), np.zeros(1), 1, 500)
+    assert e.value.status == capi.ERR_UNSUPPORTED     # beyond CVX_MAX_POINTS
+
+
+def test_full_size_config4_properties(orc):
+    """BASELINE config 4 (8 cameras, 10 000 views, 1.08 M observations) at full size: size-independent properties
+    plus a direct oracle comparison on a slice."""
+    d = cvx_amd.synth_calib(8, 1250, 12, 9, 20260004)
+    assert d["N"] == 1080000
+    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 8, 108)
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    cost, r, Jc, Jp, Jx = g.evaluate()
+    # (1) the reduction: cost kernel == 1/2 sum r^2 summed on the host in a different order
+    ref = 0.5 * float(np.sum(r.astype(np.longdouble) ** 2))
+    assert abs(g.cost() - ref) <= 1e-13 * ref and abs(cost - ref) <= 1e-13 * ref
+    # (2) a slice against the oracle: the first 40 views of camera 0 and the last 40 of camera 7
+    for v0, v1 in ((0, 40), (d["V"] - 40, d["V"])):
+        o0, o1 = d["view_off"][v0], d["view_off"][v1]
+        o = orc.Calib(d["cam_of_view"][v0:v1], d["view_off"][v0:v1 + 1] - o0, d["point_id"][o0:o1],
+                      d["obs_x"][o0:o1], d["obs_y"][o0:o1], 8, 108)
+        ro, Jco, Jpo, Jxo = o.eval(d["intr_init"], d["poses_init"][v0:v1], d["points_init"])
+        assert rel_err(r[o0:o1], ro) < 1e-12 and rel_err(Jc[o0:o1], Jco) < 1e-12
+        assert rel_err(Jp[o0:o1], Jpo) < 1e-12 and rel_err(Jx[o0:o1], Jxo) < 1e-12
+    # (3) additivity over view shards: cost(A) + cost(B) == cost(all)
+    first = cvx_amd.partition_views(d["view_off"], 2)
+    parts = 0.0
+    for rank in range(2):
+        sh = cvx_amd.shard_calib(d, first, rank)
+        gs = cvx_amd.Calib(sh["cam_of_view"], sh["view_off"], sh["point_id"], sh["obs_x"], sh["obs_y"], 8, 108)
+        gs.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
+        parts += gs.cost()
+        gs.close()
+    assert abs(parts - ref) <= 1e-13 * ref
+    # (4) the solve: monotone accepted costs, the value refine() returns settles at the noise floor
+    #     1/2 sqrt(2 sigma^2) = 0.0707 px for sigma = 0.1 px (calibration.cpp:463), and the intrinsics come back
+    s = g.solve(capi.options("refine"))
+    tr = s.trace()
+    acc = tr["cost"][tr["accepted"] > 0]
+    assert s.termination in (1, 2, 3) and s.num_successful >= 5
+    assert np.all(np.diff(acc) <= 1e-9 * acc[:-1])
+    rms = capi.lib().cvx_calib_refine_return(s.final_cost, d["N"])
+    assert abs(rms - 0.5 * np.sqrt(2) * 0.1) < 0.02 * 0.0707
+    intr = g.get_params()[0]
+    assert np.allclose(intr[:, :4], d["intr_gt"][:, :4], rtol=2e-3)
+    # (5) idempotence: solving again from the optimum terminates at once with the same cost
+    s2 = g.solve(capi.options("refine"))
+    assert s2.iterations <= 2 and abs(s2.final_cost - s.final_cost) <= 1e-9 * s.final_cost
+    g.close()

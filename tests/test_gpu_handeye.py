@@ -1,0 +1,101 @@
+"""GPU parity tests of the hand-eye AX = XB refinement through the C ABI against the oracle."""
+import numpy as np
+import pytest
+
+import cvx_amd
+from cvx_amd import capi
+from conftest import load_golden
+from test_helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n, seed, moving, orc):
+    G, T, xg, x0 = cvx_amd.synth_handeye(n, seed, moving=moving)
+    A, B = cvx_amd.handeye_pairs(G, T, moving=moving)
+    qa, ta, qb, tb = cvx_amd.pairs_to_quat_trans(A, B)
+    return cvx_amd.HandEye(qa, ta, qb, tb), orc.HandEye(qa, ta, qb, tb), (qa, ta, qb, tb), xg, x0
+
+
+@pytest.mark.parametrize("moving", [True, False])   # BASELINE config 2: 200 poses -> 199 / <=19 900 pairs
+def test_config2_matches_oracle(orc, moving):
+    g, o, (qa, ta, qb, tb), xg, x0 = make(200, 20260002, moving, orc)
+    assert g.n == (199 if moving else g.n) and g.n <= 19900
+    assert abs(g.cost(x0) - o.cost(x0)) <= 1e-13 * o.cost(x0)
+    H, gr, c = g.normal_eq(x0)
+    Ho, go, co = o.normal_eq(x0)
+    assert rel_err(H, Ho) < 1e-12 and rel_err(gr, go) < 1e-12 and abs(c - co) <= 1e-13 * co
+    r, Jq, Jt = g.evaluate(x0)
+    for i in range(0, g.n, max(1, g.n // 300)):
+        ro, Jqo, Jto = orc.handeye(x0[:4], x0[4:], qa[i], ta[i], qb[i], tb[i])
+        assert np.max(np.abs(r[i] - ro)) <= 1e-15 and np.max(np.abs(Jq[i] - Jqo)) <= 4e-15 and np.array_equal(Jt[i], Jto)
+    for kind in ("handeye", "levmar"):
+        p, s = g.solve(x0, capi.options(kind))
+        po, so = o.solve(x0, orc.options(kind))
+        assert (s.iterations, s.termination) == (so.iterations, so.termination)
+        n = min(s.trace_len, so.trace_len)
+        assert np.all(np.abs(s.trace()["cost"][:n] - so.trace()["cost"][:n]) <= 1e-12 * so.trace()["cost"][:n])
+        assert abs(s.final_cost - so.final_cost) <= 1e-12 * so.final_cost
+        assert np.max(np.abs(p - po)) <= 1e-12          # final X (q, t): 1e-9 asked
+        assert np.max(np.abs(p - xg)) < 2e-3            # and it is the ground truth up to the pose noise
+    g.close()
+
+
+def test_functor_against_50_digit_fixture():
+    f = load_golden("functor_mp.json")["handeye"]
+    qa = np.array([p["qa"] for p in f["pairs"]]); ta = np.array([p["ta"] for p in f["pairs"]])
+    qb = np.array([p["qb"] for p in f["pairs"]]); tb = np.array([p["tb"] for p in f["pairs"]])
+    g = cvx_amd.HandEye(qa, ta, qb, tb)
+    r, Jq, Jt = g.evaluate(np.array(f["p"]))     # q deliberately not unit norm: no normalisation may happen
+    rexp = np.array([[float(s) for s in p["r"]] for p in f["pairs"]])
+    Jexp = np.array([[[float(s) for s in row] for row in p["J"]] for p in f["pairs"]])
+    assert np.max(np.abs(r - rexp)) <= 1e-14
+    assert np.max(np.abs(np.concatenate([Jq, Jt], axis=2) - Jexp)) <= 2e-14
+    g.close()
+
+
+def test_golden_levmar_run_through_the_device_functor(orc):
+    """Reference levmar's recorded run on the hand-eye functor (tests/golden/levmar_handeye_trace.json) replayed
+    by the oracle's dense levmar restatement with residuals and Jacobians served by the HIP evaluation kernel."""
+    gold = load_golden("levmar_handeye_trace.json")
+    sp = gold["spec"]
+    g, o, _, xg, x0 = make(sp["n_poses"], sp["seed"], sp["moving"], orc)
+    n = g.n
+    assert n == gold["n_pairs"]
+
+    def func(p, hx, m, nn, _):
+        r, _, _ = g.evaluate(np.array([p[i] for i in range(7)]))
+        np.ctypeslib.as_array(hx, shape=(nn,))[:] = r.reshape(-1)
+
+    def jac(p, out, m, nn, _):
+        _, Jq, Jt = g.evaluate(np.array([p[i] for i in range(7)]))
+        np.ctypeslib.as_array(out, shape=(nn, 7))[:] = np.concatenate([Jq, Jt], axis=2).reshape(nn, 7)
+    p = x0.copy(); x = np.zeros(12 * n); opts = np.array(gold["opts"]); info = np.zeros(10)
+    dp = orc.c_double_p
+    orc.lib().orc_lm_nielsen_der(orc.LM_FUNC(func), orc.LM_FUNC(jac), p.ctypes.data_as(dp), x.ctypes.data_as(dp), 7, 12 * n,
+                                 gold["itmax"], opts.ctypes.data_as(dp), info.ctypes.data_as(dp), None)
+    assert int(info[6]) == int(gold["info"][6]) and abs(int(info[5]) - int(gold["info"][5])) <= 1
+    assert abs(info[1] - gold["info"][1]) <= 1e-10 * gold["info"][1]
+    assert np.max(np.abs(p - gold["p"])) <= 1e-9
+    g.close()
+
+
+def test_edge_cases():
+    # no pairs at all: zero cost, solve terminates on the gradient test
+    g = cvx_amd.HandEye(np.zeros((0, 4)), np.zeros((0, 3)), np.zeros((0, 4)), np.zeros((0, 3)))
+    x0 = np.array([1.0, 0, 0, 0, 0.1, 0.2, 0.3])
+    assert g.cost(x0) == 0.0
+    p, s = g.solve(x0)
+    assert s.termination == 1 and np.array_equal(p, x0)
+    g.close()
+    # one pair, and a pair count that is not a multiple of the wave / block size
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 257, 1025):
+        qa = rng.normal(size=(n, 4)); qa /= np.linalg.norm(qa, axis=1, keepdims=True)
+        qb = rng.normal(size=(n, 4)); qb /= np.linalg.norm(qb, axis=1, keepdims=True)
+        ta = rng.normal(size=(n, 3)); tb = rng.normal(size=(n, 3))
+        g = cvx_amd.HandEye(qa, ta, qb, tb); o = orc.HandEye(qa, ta, qb, tb)
+        H, gr, c = g.normal_eq(x0); Ho, go, co = o.normal_eq(x0)
+        assert rel_err(H, Ho) < 1e-12 and rel_err(gr, go) < 1e-12 and abs(c - co) <= 1e-13 * co
+        g.close()

@@ -1,0 +1,221 @@
+"""CPU: pins the oracle (oracle/cvx_oracle.c) against the committed golden fixtures.
+
+  * levmar_kat.json            -- the reference's own levmar 2.5 on its demo problems (known answers at
+                                  levmar/lmdemo.c:49-230 and modules/util/test/test_lm.cpp:62)
+  * levmar_calib_trace.json / levmar_handeye_trace.json -- reference levmar on the two hot-path functors
+  * functor_mp.json            -- 50-digit values of the functors and Jacobians
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_helpers import KAT_FUNCS, calib_from_fixture, rel_err
+
+
+def _run_oracle_levmar(orc, f, j, p0, x, itmax, opts):
+    evals = []
+    xv = np.array(x, dtype=np.float64)
+
+    def func(p, hx, m, n, _):
+        v = f([p[i] for i in range(m)], n)
+        for i in range(n):
+            hx[i] = v[i]
+        evals.append(float(sum((xv[i] - v[i]) ** 2 for i in range(n))))
+
+    def jac(p, out, m, n, _):
+        J = j([p[i] for i in range(m)], n)
+        for i in range(n):
+            for k in range(m):
+                out[i * m + k] = J[i][k]
+    p = np.array(p0, dtype=np.float64)
+    o = np.array(opts, dtype=np.float64)
+    info = np.zeros(10)
+    dp = orc.c_double_p
+    ret = orc.lib().orc_lm_nielsen_der(orc.LM_FUNC(func), orc.LM_FUNC(jac), p.ctypes.data_as(dp), xv.ctypes.data_as(dp),
+                                       len(p), len(xv), itmax, o.ctypes.data_as(dp), info.ctypes.data_as(dp), None)
+    return ret, p, info, evals
+
+
+@pytest.mark.parametrize("name", ["modified_rosenbrock", "powell", "meyer", "osborne", "helical_valley", "rosenbrock"])
+def test_levmar_restatement_matches_reference_levmar(orc, name):
+    g = load_golden("levmar_kat.json")[name]
+    f, j = KAT_FUNCS[name]
+    ret, p, info, evals = _run_oracle_levmar(orc, f, j, g["p0"], g["x"], g["itmax"], g["opts"])
+    # The restatement follows levmar's summation orders (lm_core.c:217-237, misc_core.c:80-132,712-798), its LU
+    # (Axb_core.c:992-1139) and its constants (lm.c:35-36), so on the same callbacks it is BIT-identical to the
+    # reference library: every evaluated |e|^2, the final parameters and info[0..9].
+    assert ret == g["ret"]
+    assert evals == g["evals"]
+    assert p.tolist() == g["p"]
+    assert info.tolist() == g["info"]
+    # and the reference's stated minima (lmdemo.c comments, test_lm.cpp:62), where levmar reaches them
+    if name in ("osborne", "helical_valley", "modified_rosenbrock", "powell"):
+        assert np.allclose(p, g["stated_minimum"], atol=2e-4)
+
+
+def test_meyer_known_answer(orc):
+    # SURVEY.md section 6 / BASELINE.md: solution (2.481778, 6.181346, 3.502236), |e|^2 = 8.79459e-05
+    g = load_golden("levmar_kat.json")["meyer"]
+    f, j = KAT_FUNCS["meyer"]
+    ret, p, info, _ = _run_oracle_levmar(orc, f, j, g["p0"], g["x"], g["itmax"], g["opts"])
+    assert np.allclose(p, [2.481778, 6.181346, 3.502236], atol=2e-6)
+    assert abs(info[1] - 8.79459e-05) < 1e-9
+
+
+def test_calib_functor_against_50_digit_values(orc):
+    g = load_golden("functor_mp.json")["calib"]
+    for ob in g["obs"]:
+        v, p = ob["view"], ob["point"]
+        intr = g["cameras"][g["cam_of_view"][v]]
+        rexp = np.array([float(s) for s in ob["r"]])
+        Jexp = np.array([[float(s) for s in row] for row in ob["J"]])
+        for autodiff in (False, True):
+            r, Jc, Jp, Jx = orc.reproj(intr, g["poses"][v], g["points"][p], ob["ox"], ob["oy"], autodiff=autodiff)
+            J = np.concatenate([Jc, Jp, Jx], axis=1)
+            # residuals are differences of ~1e3-pixel quantities: absolute tolerance in pixels
+            assert np.all(np.abs(r - rexp) <= 2e-12 * 1e3), (v, p, autodiff)
+            # the point-2 pose has |w| ~ 1e-9 < sqrt(eps): first-order branch, Jacobian of THAT expression
+            scale = np.maximum(np.abs(Jexp), np.max(np.abs(Jexp), axis=1, keepdims=True) * 1e-3)
+            assert np.all(np.abs(J - Jexp) <= 5e-12 * scale), (v, p, autodiff, np.max(np.abs(J - Jexp) / scale))
+
+
+def test_handeye_functor_against_50_digit_values(orc):
+    g = load_golden("functor_mp.json")["handeye"]
+    p = np.array(g["p"])
+    for pr in g["pairs"]:
+        rexp = np.array([float(s) for s in pr["r"]])
+        Jexp = np.array([[float(s) for s in row] for row in pr["J"]])
+        for autodiff in (False, True):
+            r, Jq, Jt = orc.handeye(p[:4], p[4:], pr["qa"], pr["ta"], pr["qb"], pr["tb"], autodiff=autodiff)
+            assert np.all(np.abs(r - rexp) <= 1e-14)
+            assert np.all(np.abs(np.concatenate([Jq, Jt], axis=1) - Jexp) <= 2e-14)
+
+
+def test_analytic_vs_autodiff_vs_central_differences(orc):
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        intr = np.array([1000, 1005, 640, 480, -0.12, 0.05, 0.01, 1e-3, -1.5e-3]) * (1 + 0.05 * rng.normal(size=9))
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        pose = np.concatenate([ax * rng.uniform(0, 1.0), [rng.uniform(-150, 150), rng.uniform(-100, 100), rng.uniform(500, 900)]])
+        X = np.array([rng.uniform(0, 275), rng.uniform(0, 200), rng.uniform(-5, 5)])
+        ra, Jca, Jpa, Jxa = orc.reproj(intr, pose, X, 600.0, 400.0)
+        rd, Jcd, Jpd, Jxd = orc.reproj(intr, pose, X, 600.0, 400.0, autodiff=True)
+        assert rel_err(ra, rd) < 1e-13
+        for a, b in ((Jca, Jcd), (Jpa, Jpd), (Jxa, Jxd)):
+            assert rel_err(a, b) < 1e-12
+        x0 = np.concatenate([intr, pose, X])
+        Jn = np.zeros((2, 18))
+        for k in range(18):
+            h = 1e-6 * max(1.0, abs(x0[k]))
+            xp, xm = x0.copy(), x0.copy()
+            xp[k] += h; xm[k] -= h
+            rp = orc.reproj(xp[:9], xp[9:15], xp[15:], 600.0, 400.0)[0]
+            rm = orc.reproj(xm[:9], xm[9:15], xm[15:], 600.0, 400.0)[0]
+            Jn[:, k] = (rp - rm) / (2 * h)
+        Ja = np.concatenate([Jca, Jpa, Jxa], axis=1)
+        assert np.all(np.abs(Ja - Jn) <= 1e-6 * np.maximum(np.abs(Ja), 1.0))
+
+
+def test_schur_lm_reproduces_reference_levmar_on_config1(orc):
+    """The oracle's Schur-structured normal equations + Nielsen damping follow the dense reference levmar
+    (same candidate-cost sequence) on BASELINE config 1."""
+    import cvx_amd
+    g = load_golden("levmar_calib_trace.json")
+    d = cvx_amd.synth_calib(**g["spec"])
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    intr, poses, pts, s = o.solve(d["intr_init"], d["poses_init"], d["points_init"], orc.options("levmar"))
+    ref_costs = 0.5 * np.array(g["evals"])       # evals[0] is the initial point, then one per linear solve
+    assert abs(s.initial_cost - ref_costs[0]) <= 1e-12 * ref_costs[0]
+    tr = s.trace()["cost"]
+    # The problem has a 7-dimensional gauge null space (free board points, calibration.cpp:391-398), so late
+    # iterations wander along it differently under LU vs Schur+Cholesky; the cost sequence still agrees
+    n = min(len(tr), len(ref_costs) - 1, 12)
+    assert n >= 10
+    assert np.all(np.abs(tr[:n] - ref_costs[1:n + 1]) <= 1e-6 * ref_costs[1:n + 1])
+    assert abs(s.final_cost - 0.5 * g["info"][1]) <= 1e-9 * s.final_cost
+    # intrinsics are gauge-invariant enough to compare: fx fy cx cy k1 k2 p1 p2 of the reference run
+    ref_intr = np.array(g["p"][:8])
+    got = intr[0, [0, 1, 2, 3, 4, 5, 7, 8]]
+    assert np.allclose(got, ref_intr, rtol=2e-4)
+
+
+def test_dense_levmar_restatement_on_handeye_functor(orc):
+    import cvx_amd
+    g = load_golden("levmar_handeye_trace.json")
+    sp = g["spec"]
+    G, T, xg, x0 = cvx_amd.synth_handeye(sp["n_poses"], sp["seed"], moving=sp["moving"])
+    A, B = cvx_amd.handeye_pairs(G, T, moving=sp["moving"])
+    assert len(A) == g["n_pairs"]
+    qa, ta, qb, tb = cvx_amd.pairs_to_quat_trans(A, B)
+    n = len(A)
+
+    def f(p, n_):
+        p = np.array(p)
+        return np.concatenate([orc.handeye(p[:4], p[4:], qa[i], ta[i], qb[i], tb[i])[0] for i in range(n)]).tolist()
+
+    def j(p, n_):
+        p = np.array(p)
+        rows = []
+        for i in range(n):
+            _, Jq, Jt = orc.handeye(p[:4], p[4:], qa[i], ta[i], qb[i], tb[i])
+            rows.extend(np.concatenate([Jq, Jt], axis=1).tolist())
+        return rows
+    ret, p, info, evals = _run_oracle_levmar(orc, f, j, x0.tolist(), [0.0] * (12 * n), g["itmax"], g["opts"])
+    # bit-identical to the reference library on the hand-eye functor (blocked J^T J path, 2388 x 7)
+    assert info.tolist() == g["info"]
+    assert p.tolist() == g["p"]
+    # (the logged |e|^2 are summed by the logging callback, in a different order than the generator's)
+    assert np.allclose(evals, g["evals"], rtol=1e-13, atol=0)
+
+
+def test_reduced_system_equals_dense_schur_complement(orc):
+    import cvx_amd
+    d = cvx_amd.synth_calib(2, 3, 5, 4, 99, ragged=3)
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    J = o.dense_jacobian(d["intr_init"], d["poses_init"], d["points_init"])
+    r = o.eval(d["intr_init"], d["poses_init"], d["points_init"])[0].reshape(-1)
+    # dense ordering: [intrinsics | poses | points]; shared ordering: [intrinsics | points]
+    nc, npz = 8 * d["C"], 6 * d["V"]
+    sh = np.r_[0:nc, nc + npz:J.shape[1]]
+    po = np.r_[nc:nc + npz]
+    H = J.T @ J
+    g = J.T @ r
+    rng = np.random.default_rng(0)
+    Ds, Dp = rng.uniform(0.1, 1.0, len(sh)), rng.uniform(0.1, 1.0, len(po))
+    Hss, Hsp, Hpp = H[np.ix_(sh, sh)] + np.diag(Ds), H[np.ix_(sh, po)], H[np.ix_(po, po)] + np.diag(Dp)
+    S_ref = Hss - Hsp @ np.linalg.solve(Hpp, Hsp.T)
+    g_ref = g[sh] - Hsp @ np.linalg.solve(Hpp, g[po])
+    S, gred, cost = o.reduced_system(d["intr_init"], d["poses_init"], d["points_init"], Dp, Ds)
+    assert rel_err(S, S_ref) < 1e-11
+    assert rel_err(gred, g_ref) < 1e-11
+    assert abs(cost - 0.5 * r @ r) <= 1e-13 * cost
+
+
+def test_dense_levmar_restatement_on_calibration_functor(orc):
+    """Reference levmar vs its restatement, both driven by the oracle's reprojection callbacks on BASELINE
+    config 1 (2160 residuals x 291 parameters, the blocked J^T J path): bit-identical."""
+    import cvx_amd
+    from test_helpers import _gen
+    g = load_golden("levmar_calib_trace.json")
+    d = cvx_amd.synth_calib(**g["spec"])
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    V, P = d["V"], d["P"]
+    cols = [0, 1, 2, 3, 4, 5, 7, 8]
+
+    def unpack(p):
+        intr = d["intr_init"].copy()
+        intr[0, cols] = p[:8]
+        return intr, np.array(p[8:8 + 6 * V]).reshape(V, 6), np.array(p[8 + 6 * V:]).reshape(P, 3)
+
+    def f(p, n):
+        return o.eval(*unpack(np.array(p)))[0].reshape(-1).tolist()
+
+    def j(p, n):
+        return o.dense_jacobian(*unpack(np.array(p)))
+    p0 = np.concatenate([d["intr_init"][:, cols].reshape(-1), d["poses_init"].reshape(-1), d["points_init"].reshape(-1)])
+    ret, p, info, evals = _run_oracle_levmar(orc, f, j, p0.tolist(), [0.0] * g["n"], g["itmax"], g["opts"])
+    assert info.tolist() == g["info"]
+    assert p.tolist() == g["p"]
+    assert np.allclose(evals, g["evals"], rtol=1e-13, atol=0)
