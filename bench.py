@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- the cvx_calibration LM inner loop on MI355X, measured as BASELINE.json asks.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE Levenberg-Marquardt iteration of CameraCalibration::refine
+(/root/reference/modules/calib/src/calibration.cpp:354-464) over one rank's shard:
+linearise (residual + Jacobian of every observation, normal-equation blocks, Schur
+contraction), exchange + solve the damped reduced system, back-substitute the poses and
+evaluate the candidate cost.  Workload: BASELINE config 4 -- 8 cameras x 1 250 views of a
+12x9 board = 10 000 pose blocks, 1 080 000 observations PER GPU (weak scaling: view shards,
+replicated shared block, one all-reduce of the reduced system per iteration).
+
+Rank 0 prints one JSON line.  `value` = observations processed by LM iterations per second,
+whole job (N ranks x 1.08 M observations x K iterations / max-over-ranks time); inputs are
+resident in HBM before the timed region.  `roofline` is for the kernel that dominates the
+iteration (per-launch hipEvent durations on the handle's stream); `eval` carries the
+materialised residual/Jacobian evaluation (HBM-bound, 328 B/observation); `cpu_baseline`
+is the oracle (CPU restatement, 1 thread, as the reference's Ceres runs) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+CAMERAS, VIEWS_PER_CAMERA, BOARD_W, BOARD_H = 8, 1250, 12, 9      # BASELINE config 4
+SEED = 20260004
+ITERS_PER_SOLVE = 10          # every timed solve restarts from the perturbed initial guess
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+F64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = FP64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+EVAL_BYTES_PER_OBS = 328      # 24 B read + 16 B residual + 288 B Jacobian
+
+
+class _DevBuf:
+    """a raw device pointer as something torch.as_tensor can wrap without copying"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def make_hook(torch, dist, capi):
+    """cvx_allreduce_fn on torch.distributed (backend nccl = RCCL over xGMI)."""
+    def hook(ctx, buf, count, on_device, stream):
+        try:
+            if on_device:
+                t = torch.as_tensor(_DevBuf(C.cast(buf, C.c_void_p).value, count), device="cuda")
+                dist.all_reduce(t)
+            else:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                t = torch.from_numpy(a).cuda()
+                dist.all_reduce(t)
+                a[:] = t.cpu().numpy()
+            return 0
+        except Exception as e:      # the C side turns this into CVX_ERR_EXCHANGE
+            sys.stderr.write("exchange hook failed: %r\n" % (e,))
+            return 1
+    return capi.ALLREDUCE_FN(hook)
+
+
+def cpu_baseline(views_per_camera, iters):
+    """The oracle's LM iterations on a bounded sample of the same workload, one thread."""
+    import cvx_amd
+    from oracle import oracle as orc
+    d = cvx_amd.synth_calib(CAMERAS, views_per_camera, BOARD_W, BOARD_H, SEED)
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], CAMERAS, BOARD_W * BOARD_H)
+    op = orc.options("refine")
+    op.max_iterations = iters
+    op.function_tolerance = op.gradient_tolerance = op.parameter_tolerance = -1.0
+    t = time.perf_counter()
+    s = o.solve(d["intr_init"], d["poses_init"], d["points_init"], op)[3]
+    dt = time.perf_counter() - t
+    return {"value": d["N"] * s.iterations / dt, "unit": "observations/s", "cores": 1, "kind": "port",
+            "sample": "config 4 cut to %d of %d views per camera (%d observations), %d LM iterations, %.1f s" % (
+                views_per_camera, VIEWS_PER_CAMERA, d["N"], s.iterations, dt),
+            "lm_iterations_per_s_at_full_size": (d["N"] * s.iterations / dt) / (CAMERAS * VIEWS_PER_CAMERA * BOARD_W * BOARD_H)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=400, help="views per camera of the CPU sample")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--host-exchange", action="store_true", help="all-reduce host copies instead of device buffers")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import cvx_amd
+    from cvx_amd import capi
+
+    if capi.lib().cvx_device_count() < 1:
+        sys.exit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- this rank's shard of the global problem: its own 10 000 views, the shared block replicated ----
+    d = cvx_amd.synth_calib(CAMERAS, VIEWS_PER_CAMERA, BOARD_W, BOARD_H, SEED + 1000 * rank)
+    intr0, pts0 = d["intr_init"].copy(), d["points_init"].copy()
+    if world > 1:       # every rank must start from the same shared parameters
+        t = torch.from_numpy(np.concatenate([intr0.ravel(), pts0.ravel()])).cuda()
+        dist.broadcast(t, 0)
+        flat = t.cpu().numpy()
+        intr0 = flat[:intr0.size].reshape(intr0.shape).copy()
+        pts0 = flat[intr0.size:].reshape(pts0.shape).copy()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], CAMERAS,
+                          BOARD_W * BOARD_H, device=local_rank, stream=stream.cuda_stream)
+        hook = None
+        if world > 1:
+            hook = make_hook(torch, dist, capi)
+            g.set_exchange(hook, rank, world, device_buffers=not a.host_exchange)
+        opt = capi.options("refine")
+        opt.function_tolerance = opt.gradient_tolerance = opt.parameter_tolerance = -1.0   # run every iteration asked
+
+        def run(n_steps):
+            done = 0
+            while done < n_steps:
+                k = min(ITERS_PER_SOLVE, n_steps - done)
+                opt.max_iterations = k
+                g.set_params(intr0, d["poses_init"], pts0)
+                s = g.solve(opt)
+                if s.iterations != k:
+                    raise RuntimeError("solve stopped after %d of %d iterations (termination %d)" % (s.iterations, k, s.termination))
+                done += k
+            return s
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        run(a.warmup)
+        g.enable_timing(True)
+        fence()
+        t0 = time.perf_counter()
+        last = run(a.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        phases = g.phase_times()
+        g.enable_timing(False)
+        geo = g.geometry()
+
+        # ---- evaluation mode: residuals + Jacobian blocks materialised in HBM (k_eval), hipEvent-timed ----
+        g.set_params(intr0, d["poses_init"], pts0)
+        g.evaluate_device()
+        torch.cuda.synchronize()
+        n_eval = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n_eval):
+            g.evaluate_device()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        eval_ms = e0.elapsed_time(e1) / n_eval
+        g.close()
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        N = d["N"]
+        V = d["V"]
+        ns = geo["ns"]
+        # algorithmic work of one launch of each phase kernel (DESIGN.md "Kernels")
+        work = {
+            # Z^T Z over the upper triangle of the (ns + 1) columns (reduced matrix + gradient column)
+            "schur": ("mfma", 2.0 * 6 * V * (ns + 1) * (ns + 2) / 2, "TFLOP/s", F64_PEAK_TFLOPS, 1e12),
+            # residual + Jacobian + 16x16 Gram + point blocks: SURVEY.md 8(d) 1 100 flop / observation
+            "normal_eq": ("mfma", 1100.0 * N, "TFLOP/s", F64_PEAK_TFLOPS, 1e12),
+            # slab reduction + assembly: read every partial tile once, write S once
+            "assemble": ("hbm", 8.0 * (geo["n_chunks"] * geo["tile_pairs"] * 48 * 48 + ns * ns), "GB/s", HBM_PEAK_GBS, 1e9),
+            "backsubst": ("hbm", 8.0 * 6 * V * geo["ZC"], "GB/s", HBM_PEAK_GBS, 1e9),
+            "cost": ("hbm", 24.0 * N, "GB/s", HBM_PEAK_GBS, 1e9),
+        }
+        per_launch = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()}
+        per_iter = {k: phases[k][0] / a.steps for k in phases}
+        dom = max(per_iter, key=lambda k: per_iter[k])
+        bound, amount, unit, peak, scale = work[dom]
+        achieved = amount / (per_launch[dom] * 1e-3) / scale if per_launch[dom] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "LM iterations/sec + residual/Jacobian evals/sec at 1M obs (observations processed by LM iterations per second)",
+            "value": world * N * a.steps / dt,
+            "unit": "observations/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps,
+            "lm_iterations_per_s": a.steps / dt,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: 8 cameras x 1250 views x 12x9 board per GPU "
+                                   "(10000 pose blocks, 1080000 observations, 388 shared unknowns), "
+                                   "CameraCalibration::refine LM iteration, k3 fixed, board points free",
+                       "observations_per_gpu": N, "views_per_gpu": V, "shared_unknowns": ns,
+                       "parallelism": "views sharded over %d GPU(s), one all-reduce of the reduced system per iteration" % world,
+                       "final_cost_after_%d_iterations" % ITERS_PER_SOLVE: last.final_cost},
+            "roofline": {"kernel": {"schur": "k_schur_syrk", "normal_eq": "k_normal_eq", "assemble": "k_ureduce+k_assemble",
+                                    "backsubst": "k_backsubst", "cost": "k_cost"}[dom],
+                         "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "avg_launch_ms": per_launch[dom], "algorithmic_per_launch": amount},
+            "phases_ms_per_iteration": per_iter,
+            "device_ms_per_iteration": sum(per_iter.values()),
+            "eval": {"kernel": "k_eval", "ms": eval_ms, "observations_per_s": N / (eval_ms * 1e-3),
+                     "roofline": {"bound": "hbm", "achieved": EVAL_BYTES_PER_OBS * N / (eval_ms * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": EVAL_BYTES_PER_OBS * N / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_views, a.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
