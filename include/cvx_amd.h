@@ -9,7 +9,7 @@
  *       modules/calib/include/cvx/calib/calibration.hpp:33, impl modules/calib/src/calibration.cpp:354-464
  *   bool HandEyeCalibration::solveFixed / solveMoving(...)
  *       modules/calib/include/cvx/calib/handeye.hpp:25-30, impl modules/calib/src/handeye.cpp:665-764
- * binds (see INTEGRATION.md and cvx_amd/include/cvx_amd/calib_adaptor.hpp).
+ * binds (see INTEGRATION.md and include/cvx_amd_adaptor.hpp).
  *
  * Every function returns a cvx_status (0 = ok) unless stated.  All host
  * pointers; device memory is owned by the handles.  Handles are

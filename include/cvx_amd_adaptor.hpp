@@ -1,0 +1,206 @@
+// cvx_amd_adaptor.hpp -- header-only C++ adaptor that keeps the signatures of
+//   double cvx::camera::CameraCalibration::refine(const Data&, PinholeCamera&, std::vector<Eigen::Matrix4d>&, bool)
+//       /root/reference/modules/calib/include/cvx/calib/calibration.hpp:33, impl calibration.cpp:354-464
+//   bool   cvx::camera::HandEyeCalibration::solveNonLinear(A, B, X)
+//       /root/reference/modules/calib/include/cvx/calib/handeye.hpp:43, impl handeye.cpp:272-333
+// and runs them on libcvx_amd.so through the C ABI of include/cvx_amd.h.
+//
+// The bodies are templates over the reference's own types, touched only through the member
+// names the reference uses (Data::coords_, Data::markers_, Marker::pt_, Marker::id_,
+// PinholeCamera::fx()/getDistortion()/setMatrix()..., Matrix4d::operator()(r,c),
+// Affine3d::matrix()).  OpenCV and Eigen are absent from the build image, so the camera
+// accessors go through `camera_traits`, whose cv::Mat specialisation is compiled only when
+// <opencv2/core.hpp> exists; tests/test_adaptor.py instantiates the templates with small
+// stand-in structs of the same shape.
+//
+// Error behaviour mirrors the reference: refine returns the RMS-like double
+// and hand-eye returns bool; a failure of the device path throws std::runtime_error carrying
+// cvx_status_string + cvx_last_error -- there is no CPU fallback.
+#pragma once
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cvx_amd.h"
+
+#if defined(__has_include)
+#if __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+#define CVX_AMD_HAVE_OPENCV 1
+#endif
+#endif
+
+namespace cvx_amd {
+
+inline void check(int status, const char *what) {
+    if (status != CVX_OK)
+        throw std::runtime_error(std::string(what) + ": " + cvx_status_string(status) + " [" + cvx_last_error() + "]");
+}
+
+// intrinsics block in the reference's order fx,fy,cx,cy,k1,k2,k3,p1,p2 (calibration.cpp:219-229)
+template <class Camera>
+struct camera_traits {
+    // generic form: Camera exposes fx(),fy(),cx(),cy() and a 5-element distortion in OpenCV order
+    // k1,k2,p1,p2,k3 through dist(i) / set_dist(i, v) / set_pinhole(fx,fy,cx,cy)
+    static void get(const Camera &cam, double k[9]) {
+        k[0] = cam.fx(); k[1] = cam.fy(); k[2] = cam.cx(); k[3] = cam.cy();
+        k[4] = cam.dist(0); k[5] = cam.dist(1); k[7] = cam.dist(2); k[8] = cam.dist(3); k[6] = cam.dist(4);
+    }
+    static void set(Camera &cam, const double k[9]) {
+        cam.set_pinhole(k[0], k[1], k[2], k[3]);
+        cam.set_dist(0, k[4]); cam.set_dist(1, k[5]); cam.set_dist(2, k[7]); cam.set_dist(3, k[8]); cam.set_dist(4, k[6]);
+    }
+};
+
+#ifdef CVX_AMD_HAVE_OPENCV
+// cvx::util::PinholeCamera (modules/util/include/cvx/util/camera/camera.hpp:77-188): the same reads
+// and writes as calibration.cpp:365-375 and :444-459
+template <class Camera>
+struct opencv_camera_traits {
+    static void get(const Camera &cam, double k[9]) {
+        k[0] = cam.fx(); k[1] = cam.fy(); k[2] = cam.cx(); k[3] = cam.cy();
+        cv::Mat_<double> dist(cam.getDistortion());
+        k[4] = dist(0, 0); k[5] = dist(0, 1); k[7] = dist(0, 2); k[8] = dist(0, 3); k[6] = dist(0, 4);
+    }
+    static void set(Camera &cam, const double k[9]) {
+        cv::Mat_<double> P = cv::Mat_<double>::zeros(3, 3);
+        P(0, 0) = k[0]; P(1, 1) = k[1]; P(2, 2) = 1.0; P(0, 2) = k[2]; P(1, 2) = k[3];
+        cv::Mat_<double> dist(cam.getDistortion());
+        dist(0, 0) = k[4]; dist(0, 1) = k[5]; dist(0, 2) = k[7]; dist(0, 3) = k[8]; dist(0, 4) = k[6];
+        cam.setDistortion(dist);
+        cam.setMatrix(P);
+    }
+};
+#endif
+
+struct RefineReport {
+    cvx_lm_summary summary;
+    double rms = 0.0;
+};
+
+// CameraCalibration::refine.  `Traits` reads/writes the camera; Mat4 is indexed (row, col).
+// Like the reference, the refined board points are NOT written back (calibration.cpp:377-381
+// copies coords_ into a local vector) and views without markers keep their extrinsics.
+template <class Data, class Camera, class Mat4, class Traits = camera_traits<Camera>>
+double refine(const Data &data, Camera &cam, std::vector<Mat4> &extrinsics, bool intrinsics = true,
+              int device = 0, void *stream = nullptr, RefineReport *report = nullptr) {
+    const int V = (int)data.markers_.size(), P = (int)data.coords_.size();
+    if ((int)extrinsics.size() < V) throw std::runtime_error("refine: fewer extrinsics than views");
+    std::vector<int> cam_of_view(V, 0), view_off(V + 1, 0), point_id;
+    std::vector<double> ox, oy;
+    for (int i = 0; i < V; ++i) {
+        for (const auto &m : data.markers_[i]) {
+            point_id.push_back(m.id_);
+            ox.push_back((double)m.pt_.x);      // cv::Point2f promoted to double, calibration.cpp:393
+            oy.push_back((double)m.pt_.y);
+        }
+        view_off[i + 1] = (int)point_id.size();
+    }
+    double k[9];
+    Traits::get(cam, k);
+    std::vector<double> poses(6 * (size_t)V), points(3 * (size_t)P);
+    for (int i = 0; i < V; ++i) {       // packCamerasRotationAndTranslation, calibration.cpp:318-332
+        double R[9];
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) R[3 * c + r] = extrinsics[i](r, c);
+        cvx_rotation_to_angle_axis(R, &poses[6 * i]);
+        for (int r = 0; r < 3; ++r) poses[6 * i + 3 + r] = extrinsics[i](r, 3);
+    }
+    for (int p = 0; p < P; ++p) {
+        points[3 * p] = (double)data.coords_[p].x; points[3 * p + 1] = (double)data.coords_[p].y;
+        points[3 * p + 2] = (double)data.coords_[p].z;
+    }
+    cvx_calib_desc d;
+    d.n_cameras = 1; d.n_views = V; d.n_points = P; d.n_obs = (int64_t)point_id.size();
+    d.cam_of_view = cam_of_view.data(); d.view_off = view_off.data(); d.point_id = point_id.data();
+    d.obs_x = ox.data(); d.obs_y = oy.data();
+    d.fix_k3 = 1; d.fix_intrinsics = intrinsics ? 0 : 1; d.fix_points = 0;
+    d.device = device; d.stream = stream;
+    cvx_calib *h = nullptr;
+    check(cvx_calib_create(&d, &h), "cvx_calib_create");
+    struct Guard { cvx_calib *h; ~Guard() { cvx_calib_destroy(h); } } guard{h};
+    check(cvx_calib_set_params(h, k, poses.data(), points.data()), "cvx_calib_set_params");
+    cvx_lm_options opt;
+    cvx_lm_options_refine(&opt);
+    RefineReport local;
+    RefineReport &rep = report ? *report : local;
+    check(cvx_calib_solve(h, &opt, &rep.summary), "cvx_calib_solve");
+    check(cvx_calib_get_params(h, k, poses.data(), points.data()), "cvx_calib_get_params");
+    for (int i = 0; i < V; ++i) {       // unpackCamerasRotationAndTranslation, calibration.cpp:335-350
+        double R[9];
+        cvx_angle_axis_to_rotation(&poses[6 * i], R);
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) extrinsics[i](r, c) = R[3 * c + r];
+        for (int r = 0; r < 3; ++r) extrinsics[i](r, 3) = poses[6 * i + 3 + r];
+    }
+    if (intrinsics) Traits::set(cam, k);
+    rep.rms = cvx_calib_refine_return(rep.summary.final_cost, d.n_obs);   // calibration.cpp:463
+    return rep.rms;
+}
+
+// HandEyeCalibration::solveNonLinear(A, B, X): Affine is indexed through .matrix()(r, c)
+template <class Affine>
+bool solve_nonlinear(const std::vector<Affine> &A, const std::vector<Affine> &B, Affine &X, int device = 0,
+                     void *stream = nullptr, cvx_lm_summary *summary = nullptr) {
+    const int n = (int)A.size();
+    if ((int)B.size() != n) return false;
+    std::vector<double> qa(4 * (size_t)n), ta(3 * (size_t)n), qb(4 * (size_t)n), tb(3 * (size_t)n);
+    auto flat = [](const Affine &T, double M[16]) {
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) M[4 * c + r] = T.matrix()(r, c);
+    };
+    double M[16];
+    for (int i = 0; i < n; ++i) {
+        flat(A[i], M); cvx_affine_to_quat_trans(M, &qa[4 * i], &ta[3 * i]);
+        flat(B[i], M); cvx_affine_to_quat_trans(M, &qb[4 * i], &tb[3 * i]);
+    }
+    double p[7], q[4], t[3];
+    flat(X, M);
+    cvx_affine_to_quat_trans(M, q, t);
+    p[0] = q[0]; p[1] = q[1]; p[2] = q[2]; p[3] = q[3]; p[4] = t[0]; p[5] = t[1]; p[6] = t[2];
+    cvx_handeye *h = nullptr;
+    check(cvx_handeye_create(n, qa.data(), ta.data(), qb.data(), tb.data(), device, stream, &h), "cvx_handeye_create");
+    struct Guard { cvx_handeye *h; ~Guard() { cvx_handeye_destroy(h); } } guard{h};
+    cvx_lm_options opt;
+    cvx_lm_options_handeye(&opt);
+    cvx_lm_summary local;
+    check(cvx_handeye_solve(h, p, &opt, summary ? summary : &local), "cvx_handeye_solve");
+    cvx_quat_trans_to_affine(p, M);     // X = Translation(t) * q.toRotationMatrix(), handeye.cpp:326-330
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) X.matrix()(r, c) = M[4 * c + r];
+    return true;
+}
+
+// The refinement half of HandEyeCalibration::solveFixed / solveMoving (handeye.cpp:665-764):
+// builds the motion pairs exactly as the reference does and refines X, which must hold the
+// linear initial estimate on entry (the closed-form initialisers, handeye.cpp:335-599, are
+// outside the accelerated path -- SURVEY.md 8f).
+template <class Affine>
+bool solve_handeye(const std::vector<Affine> &gripper_to_base, const std::vector<Affine> &target_to_sensor,
+                   Affine &X, bool moving, int device = 0, void *stream = nullptr) {
+    const int n = (int)gripper_to_base.size();
+    if ((int)target_to_sensor.size() != n || n < 2) return false;
+    std::vector<double> G(16 * (size_t)n), T(16 * (size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) {
+                G[16 * i + 4 * c + r] = gripper_to_base[i].matrix()(r, c);
+                T[16 * i + 4 * c + r] = target_to_sensor[i].matrix()(r, c);
+            }
+    auto pairs = moving ? cvx_handeye_pairs_moving : cvx_handeye_pairs_fixed;
+    int cnt = 0;
+    check(pairs(n, G.data(), T.data(), nullptr, nullptr, 0, &cnt), "pair count");
+    std::vector<double> A(16 * (size_t)(cnt ? cnt : 1)), B(A.size());
+    check(pairs(n, G.data(), T.data(), A.data(), B.data(), cnt, &cnt), "pairs");
+    std::vector<Affine> Av(cnt, X), Bv(cnt, X);
+    for (int i = 0; i < cnt; ++i)
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) {
+                Av[i].matrix()(r, c) = A[16 * i + 4 * c + r];
+                Bv[i].matrix()(r, c) = B[16 * i + 4 * c + r];
+            }
+    return solve_nonlinear(Av, Bv, X, device, stream);
+}
+
+}  // namespace cvx_amd

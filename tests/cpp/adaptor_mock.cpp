@@ -1,0 +1,93 @@
+// Exercises include/cvx_amd_adaptor.hpp with stand-in structs that have the shape of the reference's
+// boundary types (CameraCalibration::Data calibration.hpp:18-26, CalibrationPattern::Marker
+// pattern.hpp:18-24, Eigen::Matrix4d / Affine3d): BASELINE config 1 through cvx_amd::refine and a
+// 30-pose hand-eye problem through cvx_amd::solve_handeye.  Prints one JSON line; tests/test_adaptor.py
+// compares it with the oracle.  Built by cvx_amd/csrc/Makefile (target adaptor_mock).
+#include <cstdio>
+#include <vector>
+
+#include "../../include/cvx_amd_adaptor.hpp"
+
+struct Pt2f { float x, y; };
+struct Pt3f { float x, y, z; };
+struct Marker { Pt2f pt_; int id_; };
+struct Data {
+    std::vector<Pt3f> coords_;
+    std::vector<std::vector<Marker>> markers_;
+};
+struct Mat4 {
+    double m[16];   // column-major like Eigen
+    double &operator()(int r, int c) { return m[4 * c + r]; }
+    double operator()(int r, int c) const { return m[4 * c + r]; }
+    Mat4 &matrix() { return *this; }
+    const Mat4 &matrix() const { return *this; }
+};
+struct Camera {
+    double fx_, fy_, cx_, cy_, d[5];
+    double fx() const { return fx_; } double fy() const { return fy_; }
+    double cx() const { return cx_; } double cy() const { return cy_; }
+    double dist(int i) const { return d[i]; }
+    void set_dist(int i, double v) { d[i] = v; }
+    void set_pinhole(double a, double b, double c, double e) { fx_ = a; fy_ = b; cx_ = c; cy_ = e; }
+};
+
+int main() {
+    cvx_synth_calib_spec s = {1, 20, 9, 6, 25.0, 20260001ull, 0.1, 0};
+    const int V = 20, P = 54;
+    const long long N = cvx_synth_calib_count(&s);
+    std::vector<int> cov(V), off(V + 1), pid(N);
+    std::vector<double> ox(N), oy(N), ig(9), pg(6 * V), xg(3 * P), ii(9), pi(6 * V), xi(3 * P);
+    if (cvx_synth_calib(&s, cov.data(), off.data(), pid.data(), ox.data(), oy.data(), ig.data(), pg.data(), xg.data(),
+                        ii.data(), pi.data(), xi.data()))
+        return 2;
+    Data data;
+    for (int p = 0; p < P; ++p) data.coords_.push_back({(float)xi[3 * p], (float)xi[3 * p + 1], (float)xi[3 * p + 2]});
+    data.markers_.resize(V);
+    for (int v = 0; v < V; ++v)
+        for (int o = off[v]; o < off[v + 1]; ++o) data.markers_[v].push_back({{(float)ox[o], (float)oy[o]}, pid[o]});
+    Camera cam = {ii[0], ii[1], ii[2], ii[3], {ii[4], ii[5], ii[7], ii[8], ii[6]}};
+    std::vector<Mat4> ext(V);
+    for (int v = 0; v < V; ++v) {
+        double R[9];
+        cvx_angle_axis_to_rotation(&pi[6 * v], R);
+        Mat4 &M = ext[v];
+        for (int i = 0; i < 16; ++i) M.m[i] = 0;
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) M(r, c) = R[3 * c + r];
+        for (int r = 0; r < 3; ++r) M(r, 3) = pi[6 * v + 3 + r];
+        M(3, 3) = 1;
+    }
+    cvx_amd::RefineReport rep;
+    double rms;
+    try {
+        rms = cvx_amd::refine(data, cam, ext, true, 0, nullptr, &rep);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    }
+    std::printf("{\"rms\": %.17g, \"iterations\": %d, \"final_cost\": %.17g, \"intr\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g], ",
+                rms, rep.summary.iterations, rep.summary.final_cost, cam.fx_, cam.fy_, cam.cx_, cam.cy_, cam.d[0], cam.d[1],
+                cam.d[4], cam.d[2], cam.d[3]);
+    std::printf("\"ext0\": [");
+    for (int i = 0; i < 16; ++i) std::printf("%s%.17g", i ? ", " : "", ext[0].m[i]);
+    std::printf("], ");
+
+    const int n = 30;
+    std::vector<double> G(16 * n), T(16 * n);
+    double xgt[7], x0[7];
+    if (cvx_synth_handeye(n, 20260002ull, 1e-3, 1e-4, 0, G.data(), T.data(), xgt, x0)) return 4;
+    std::vector<Mat4> Gv(n), Tv(n);
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 16; ++k) { Gv[i].m[k] = G[16 * i + k]; Tv[i].m[k] = T[16 * i + k]; }
+    Mat4 X;
+    cvx_quat_trans_to_affine(x0, X.m);
+    bool ok;
+    try {
+        ok = cvx_amd::solve_handeye(Gv, Tv, X, false);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 5;
+    }
+    std::printf("\"handeye_ok\": %d, \"X\": [", ok ? 1 : 0);
+    for (int i = 0; i < 16; ++i) std::printf("%s%.17g", i ? ", " : "", X.m[i]);
+    std::printf("]}\n");
+    return 0;
+}

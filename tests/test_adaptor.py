@@ -1,0 +1,62 @@
+"""The header-only C++ adaptor (include/cvx_amd_adaptor.hpp) that keeps the signatures of
+CameraCalibration::refine (calibration.hpp:33) and HandEyeCalibration::solveFixed (handeye.hpp:25-27).
+
+CPU: the header compiles stand-alone as C++17 and the stand-in-typed driver is built.
+GPU: the driver's refine / hand-eye results equal the oracle's on the same inputs (1e-9 relative on the
+RMS-like return value, intrinsics and extrinsics; the tolerance north_star states)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+BIN = os.path.join(ROOT, "tests", "cpp", "adaptor_mock")
+
+
+def test_header_compiles_standalone(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "cvx_amd_adaptor.hpp"\nint main() { return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)])
+    assert os.path.exists(BIN), "run __graft_entry__.build() (make -C cvx_amd/csrc)"
+
+
+@pytest.mark.gpu
+def test_adaptor_refine_and_handeye_match_oracle(orc):
+    import cvx_amd
+    out = json.loads(subprocess.check_output([BIN], timeout=100).decode())
+    d = cvx_amd.synth_calib(1, 20, 9, 6, 20260001)
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 1, 54)
+    pts = d["points_init"].astype(np.float32).astype(np.float64)
+    # the adaptor round-trips the initial poses through 4x4 matrices, as the reference does
+    poses = d["poses_init"].copy()
+    L = cvx_amd.capi.lib()
+    for v in range(d["V"]):
+        R = np.zeros(9); w = np.zeros(3)
+        L.cvx_angle_axis_to_rotation(cvx_amd.capi.pd(poses[v, :3].copy()), cvx_amd.capi.pd(R))
+        L.cvx_rotation_to_angle_axis(cvx_amd.capi.pd(R), cvx_amd.capi.pd(w))
+        poses[v, :3] = w
+    io, po, xo, so = o.solve(d["intr_init"], poses, pts, orc.options("refine"))
+    rms = orc.lib().orc_calib_refine_return(so.final_cost, d["N"])
+    assert out["iterations"] == so.iterations
+    assert abs(out["rms"] - rms) <= 1e-9 * rms
+    assert np.max(np.abs(np.array(out["intr"]) - io[0]) / np.maximum(np.abs(io[0]), 1e-6)) < 1e-9
+    R = np.zeros(9)
+    L.cvx_angle_axis_to_rotation(cvx_amd.capi.pd(po[0, :3].copy()), cvx_amd.capi.pd(R))
+    ext = np.array(out["ext0"]).reshape(4, 4).T       # column-major -> [r][c]
+    assert np.max(np.abs(ext[:3, :3] - R.reshape(3, 3).T)) < 1e-9
+    assert np.max(np.abs(ext[:3, 3] - po[0, 3:])) < 1e-9 * np.max(np.abs(po[0, 3:]))
+    # hand-eye
+    G, T, xgt, x0 = cvx_amd.synth_handeye(30, 20260002)
+    A, B = cvx_amd.handeye_pairs(G, T)
+    ho = orc.HandEye(*cvx_amd.pairs_to_quat_trans(A, B))
+    # the adaptor converts X0 to a matrix and back to a quaternion before solving
+    M = np.zeros(16); q = np.zeros(4); t = np.zeros(3)
+    L.cvx_quat_trans_to_affine(cvx_amd.capi.pd(x0.copy()), cvx_amd.capi.pd(M))
+    L.cvx_affine_to_quat_trans(cvx_amd.capi.pd(M), cvx_amd.capi.pd(q), cvx_amd.capi.pd(t))
+    p, hs = ho.solve(np.concatenate([q, t]), orc.options("handeye"))
+    L.cvx_quat_trans_to_affine(cvx_amd.capi.pd(p.copy()), cvx_amd.capi.pd(M))
+    assert out["handeye_ok"] == 1
+    assert np.max(np.abs(np.array(out["X"]) - M)) < 1e-9
