@@ -197,6 +197,8 @@ def main():
             "assemble": ("hbm", 8.0 * (geo["n_chunks"] * geo["tile_pairs"] * 48 * 48 + ns * ns), "GB/s", HBM_PEAK_GBS, 1e9),
             "backsubst": ("hbm", 8.0 * 6 * V * geo["ZC"], "GB/s", HBM_PEAK_GBS, 1e9),
             "cost": ("hbm", 24.0 * N, "GB/s", HBM_PEAK_GBS, 1e9),
+            # damped reduced solve: Cholesky ns^3 / 3 flop (latency-bound chain of tile columns)
+            "solve": ("mfma", ns ** 3 / 3.0, "TFLOP/s", F64_PEAK_TFLOPS, 1e12),
         }
         per_launch = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()}
         per_iter = {k: phases[k][0] / a.steps for k in phases}
@@ -225,8 +227,9 @@ def main():
                        "observations_per_gpu": N, "views_per_gpu": V, "shared_unknowns": ns,
                        "parallelism": "views sharded over %d GPU(s), one all-reduce of the reduced system per iteration" % world,
                        "final_cost_after_%d_iterations" % ITERS_PER_SOLVE: last.final_cost},
-            "roofline": {"kernel": {"schur": "k_schur_syrk", "normal_eq": "k_normal_eq", "assemble": "k_ureduce+k_assemble",
-                                    "backsubst": "k_backsubst", "cost": "k_cost"}[dom],
+            "roofline": {"kernel": {"schur": "k_schur_syrk", "normal_eq": "k_normal_eq", "assemble": "k_group_sum+k_assemble",
+                                    "backsubst": "k_backsubst", "cost": "k_cost",
+                                    "solve": "k_damp_prepare+k_chol_step+k_solve_finish"}[dom],
                          "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_ms": per_launch[dom], "algorithmic_per_launch": amount},

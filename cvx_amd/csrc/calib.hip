@@ -10,6 +10,7 @@
 #include "calib_kernels.h"
 #include "common.h"
 #include "lm_driver.h"
+#include "solve_kernels.h"
 
 using namespace cvxk;
 
@@ -36,7 +37,7 @@ __global__ void k_fill(double *p, long long n, double v) {
     if (i < n) p[i] = v;
 }
 
-enum { PH_NORMAL = 0, PH_SCHUR, PH_ASSEMBLE, PH_BACKSUBST, PH_COST, PH_COUNT };
+enum { PH_NORMAL = 0, PH_SCHUR, PH_ASSEMBLE, PH_BACKSUBST, PH_COST, PH_SOLVE, PH_COUNT };
 
 }  // namespace
 
@@ -54,7 +55,7 @@ struct cvx_calib {
     std::vector<int> h_cam_of_view, h_view_off;
     // device: static
     int *d_view_off = nullptr, *d_cam_of_view = nullptr, *d_point_id = nullptr, *d_view_id = nullptr;
-    int *d_grp_v0 = nullptr, *d_chk_row0 = nullptr, *d_chk_cam = nullptr, *d_glist = nullptr, *d_glist_off = nullptr;
+    int *d_grp_v0 = nullptr, *d_chk_row0 = nullptr, *d_clist = nullptr, *d_clist_off = nullptr, *d_glist = nullptr, *d_glist_off = nullptr;
     double *d_obs_x = nullptr, *d_obs_y = nullptr;
     // device: parameters (current / candidate)
     double *d_intr[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr}, *d_poses[2] = {nullptr, nullptr};
@@ -62,14 +63,18 @@ struct cvx_calib {
     // device: work
     double *d_rt = nullptr, *d_Z = nullptr, *d_Linv = nullptr, *d_Dv = nullptr, *d_gv = nullptr, *d_s2pose = nullptr;
     double *d_slab_pt = nullptr, *d_slab_cam = nullptr, *d_grp_scal = nullptr, *d_slab_tile = nullptr;
-    double *d_Ucx = nullptr, *d_Uxx = nullptr, *d_Gcam = nullptr;
+    double *d_Tpt = nullptr, *d_Tt = nullptr, *d_Gcam = nullptr;
     double *d_E = nullptr, *h_E = nullptr;
     size_t E_count = 0, E_scal = 0;
     double *d_ds_emb = nullptr, *h_ds_emb = nullptr, *d_dposes = nullptr, *d_out_view = nullptr;
     double *d_cost_partial = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
     double *d_eval = nullptr;
-    // host copies of the shared blocks
-    std::vector<double> h_intr, h_points, h_intr_cand, h_points_cand, s2_shared, Ds, delta_s, Swork, rhs;
+    // device: damped reduced solve (solve_kernels.h)
+    int npad = 32, nT = 1;
+    double *d_A = nullptr, *d_L = nullptr, *d_s2sh = nullptr, *d_Ds = nullptr, *d_delta_s = nullptr;
+    int *d_fail = nullptr;
+    size_t fin_lds = 0;
+    std::vector<double> s2_shared, h_tail, h_A;
     // exchange
     cvx_allreduce_fn xfn = nullptr;
     void *xctx = nullptr;
@@ -78,20 +83,20 @@ struct cvx_calib {
     bool timing = false;
     hipEvent_t ev[PH_COUNT][2];
     bool ev_made = false;
-    double ph_ms[PH_COUNT] = {0, 0, 0, 0, 0};
-    long long ph_n[PH_COUNT] = {0, 0, 0, 0, 0};
-    bool ph_used[PH_COUNT] = {false, false, false, false, false};
+    double ph_ms[PH_COUNT] = {0, 0, 0, 0, 0, 0};
+    long long ph_n[PH_COUNT] = {0, 0, 0, 0, 0, 0};
+    bool ph_used[PH_COUNT] = {false, false, false, false, false, false};
 
     ~cvx_calib();
 };
 
 cvx_calib::~cvx_calib() {
     (void)hipSetDevice(device);
-    void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_chk_cam, d_glist,
+    void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
-                    d_slab_tile, d_Ucx, d_Uxx, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial,
-                    d_E2, d_eval};
+                    d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial,
+                    d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -163,7 +168,9 @@ int launch_pose_prepare(cvx_calib *h, const double *poses) {
     return CVX_OK;
 }
 
-// linearise at the current point and bring E to the host.  with_schur = false leaves S = U.
+// Enqueue one linearisation at the current point: pose tables, normal-equation blocks, Schur
+// contraction, fixed-order slab sums, assembly of E, and the exchange step.  Nothing is copied to
+// the host (a host-buffer exchange hook is the exception: E makes the round trip the hook asks for).
 int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_scale) {
     int st = launch_pose_prepare(h, h->d_poses[h->cur]);
     if (st) return st;
@@ -192,24 +199,28 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
     double *scal = h->d_E + h->E_scal;
     CVX_HIP(hipMemsetAsync(scal, 0, (2 + 2 * (size_t)h->nranks) * sizeof(double), h->stream));
     {
-        URArgs u;
-        u.slab_pt = h->d_slab_pt; u.slab_cam = h->d_slab_cam; u.grp_scal = h->d_grp_scal;
-        u.glist = h->d_glist; u.glist_off = h->d_glist_off;
-        u.n_groups = h->n_groups; u.C = h->C; u.P = h->P; u.cam_free = h->cam_free; u.pts_free = h->pts_free;
-        u.Ucx = h->d_Ucx; u.Uxx = h->d_Uxx; u.Gcam = h->d_Gcam;
-        u.out_sum = scal; u.out_bad = scal + 1; u.out_gmax = scal + 2 + h->rank; u.out_dmax = scal + 2 + h->nranks + h->rank;
-        long long n = 1 + (long long)h->C * 256;
-        if (h->cam_free && h->pts_free) n += (long long)h->C * h->P * 27;
-        if (h->pts_free) n += (long long)h->P * 9;
-        hipLaunchKernelGGL(k_ureduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, u);
+        // fixed-order slab sums per camera, then the scalars of this linearisation
+        if (h->pts_free) {
+            const int n_out = h->P * PT_ACC;
+            hipLaunchKernelGGL(k_group_sum, dim3((n_out + 63) / 64, h->C), dim3(256), 0, h->stream, h->d_slab_pt,
+                               (size_t)n_out, n_out, h->d_glist, h->d_glist_off, h->d_Tpt);
+        }
+        hipLaunchKernelGGL(k_group_sum, dim3(4, h->C), dim3(256), 0, h->stream, h->d_slab_cam, (size_t)256, 256,
+                           h->d_glist, h->d_glist_off, h->d_Gcam);
+        if (schur) {
+            const int n_out = h->ntp * ZTILE * ZTILE;
+            hipLaunchKernelGGL(k_group_sum, dim3((n_out + 63) / 64, h->C), dim3(256), 0, h->stream, h->d_slab_tile,
+                               (size_t)n_out, n_out, h->d_clist, h->d_clist_off, h->d_Tt);
+        }
+        hipLaunchKernelGGL(k_lin_scalars, dim3(1), dim3(256), 0, h->stream, h->d_Gcam, h->C, h->d_grp_scal, h->n_groups,
+                           scal, scal + 1, scal + 2 + h->rank, scal + 2 + h->nranks + h->rank);
         CVX_HIP(hipGetLastError());
     }
     if (h->ns > 0) {
         AsmArgs s;
-        s.slab = h->d_slab_tile; s.Ucx = h->d_Ucx; s.Uxx = h->d_Uxx; s.Gcam = h->d_Gcam; s.chk_cam = h->d_chk_cam;
+        s.Tt = schur ? h->d_Tt : nullptr; s.Tpt = h->d_Tpt; s.Gcam = h->d_Gcam;
         s.ns = h->ns; s.C = h->C; s.P = h->P; s.ncf = h->ncf; s.fix_k3 = h->fix_k3; s.pts_free = h->pts_free;
         s.ZC = h->ZC; s.camcol0 = h->camcol0; s.ycol = h->ycol; s.nt = h->nt; s.ntp = h->ntp;
-        s.n_chunks = schur ? h->n_chunks : 0;
         s.E = h->d_E;
         const long long n = (long long)h->ns * h->ns + h->ns;
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, s);
@@ -217,46 +228,17 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
     }
     ph_end(h, PH_ASSEMBLE);
     // exchange step (view-sharded runs): one all-reduce of [S | gred | gs | diagU | scalars]
-    if (h->nranks > 1 && h->xfn && h->xdev) {
-        if (h->xfn(h->xctx, h->d_E, h->E_count, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
-    }
-    CVX_HIP(hipMemcpyAsync(h->h_E, h->d_E, h->E_count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    CVX_HIP(hipStreamSynchronize(h->stream));
-    ph_collect(h);
-    if (h->nranks > 1 && h->xfn && !h->xdev) {
-        if (h->xfn(h->xctx, h->h_E, h->E_count, 0, nullptr)) return CVX_ERR_EXCHANGE;
+    if (h->nranks > 1 && h->xfn) {
+        if (h->xdev) {
+            if (h->xfn(h->xctx, h->d_E, h->E_count, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
+        } else {
+            CVX_HIP(hipMemcpyAsync(h->h_E, h->d_E, h->E_count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            CVX_HIP(hipStreamSynchronize(h->stream));
+            if (h->xfn(h->xctx, h->h_E, h->E_count, 0, nullptr)) return CVX_ERR_EXCHANGE;
+            CVX_HIP(hipMemcpyAsync(h->d_E, h->h_E, h->E_count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
     }
     return CVX_OK;
-}
-
-struct HostLin {
-    double cost, gmax, dmax, nbad;
-    const double *S, *gred, *gs, *diagU;
-};
-
-HostLin read_E(cvx_calib *h) {
-    HostLin r;
-    const size_t nn = (size_t)h->ns * h->ns;
-    r.S = h->h_E; r.gred = h->h_E + nn; r.gs = r.gred + h->ns; r.diagU = r.gs + h->ns;
-    const double *scal = h->h_E + h->E_scal;
-    r.cost = 0.5 * scal[0];
-    r.nbad = scal[1];
-    double gm = 0, dm = 0;
-    for (int q = 0; q < h->nranks; ++q) { gm = std::max(gm, scal[2 + q]); dm = std::max(dm, scal[2 + h->nranks + q]); }
-    for (int i = 0; i < h->ns; ++i) { gm = std::max(gm, std::fabs(r.gs[i])); dm = std::max(dm, r.diagU[i]); }
-    r.gmax = gm; r.dmax = dm;
-    return r;
-}
-
-// index of shared parameter i in the host intrinsics / points arrays
-inline double *shared_ptr_of(cvx_calib *h, std::vector<double> &intr, std::vector<double> &pts, int i) {
-    const int ncam = h->C * h->ncf;
-    if (i < ncam) {
-        const int c = i / h->ncf, k = i % h->ncf;
-        const int kk = (h->fix_k3 && k >= 6) ? k + 1 : k;
-        return &intr[9 * c + kk];
-    }
-    return &pts[i - ncam];
 }
 
 class CalibEvaluator : public cvx::Evaluator {
@@ -265,6 +247,7 @@ public:
     cvx_calib *h;
     // extra outputs of the last try_step, for cvx_calib_linear_step
     bool keep_dposes = false;
+    double *want_S = nullptr;
 
     cvx::InitInfo init(bool jacobi) override {
         cvx::InitInfo out;
@@ -275,112 +258,102 @@ public:
         cvx_damping d0 = {0, 0, 0, 0};
         out.status = linearize(h, d0, true, jacobi);
         if (out.status) return out;
-        HostLin L = read_E(h);
+        // the tail of E: gred | gs | diagU | scalars
+        const size_t nn = (size_t)h->ns * h->ns, tail = h->E_count - nn;
+        h->h_tail.resize(tail);
+        if (hipMemcpyAsync(h->h_tail.data(), h->d_E + nn, tail * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { out.status = CVX_ERR_HIP; return out; }
+        ph_collect(h);
+        const double *gs = h->h_tail.data() + h->ns, *dU = gs + h->ns, *scal = h->h_tail.data() + 3 * (size_t)h->ns;
+        double gm = 0, dm = 0;
+        for (int q = 0; q < h->nranks; ++q) { gm = std::max(gm, scal[2 + q]); dm = std::max(dm, scal[2 + h->nranks + q]); }
         for (int i = 0; i < h->ns; ++i) {
-            if (jacobi) { const double s = 1.0 / (1.0 + std::sqrt(L.diagU[i])); h->s2_shared[i] = s * s; }
+            gm = std::max(gm, std::fabs(gs[i])); dm = std::max(dm, dU[i]);
+            if (jacobi) { const double s = 1.0 / (1.0 + std::sqrt(dU[i])); h->s2_shared[i] = s * s; }
             else h->s2_shared[i] = 1.0;
         }
-        out.cost = L.cost; out.grad_max = L.gmax; out.diag_max = L.dmax;
+        if (h->ns > 0 &&
+            hipMemcpyAsync(h->d_s2sh, h->s2_shared.data(), sizeof(double) * h->ns, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            out.status = CVX_ERR_HIP; return out;
+        }
+        out.cost = 0.5 * scal[0]; out.grad_max = gm; out.diag_max = dm;
         return out;
     }
 
     cvx::StepInfo try_step(const cvx_damping &d, double gtol, bool gradient_only) override {
         cvx::StepInfo out;
-        out.status = linearize(h, d, false, false);
+        out.status = run_step(d);
         if (out.status) return out;
-        HostLin L = read_E(h);
-        out.cost = L.cost; out.grad_max = L.gmax;
-        if (L.gmax <= gtol) { out.grad_converged = true; return out; }
+        const double *R = h->h_E2;
+        out.cost = 0.5 * R[11];
+        out.grad_max = std::max(R[9], R[13]);
+        if (out.grad_max <= gtol) { out.grad_converged = true; return out; }
         if (gradient_only) return out;
-        const int ns = h->ns;
-        // norms of the current point
-        double xs2 = 0, fs2 = 0;
-        if (h->cam_free) {
-            for (double v : h->h_intr) xs2 += v * v;
-            for (int c = 0; c < h->C; ++c)
-                for (int k = 0; k < 9; ++k)
-                    if (!(h->fix_k3 && k == 6)) fs2 += h->h_intr[9 * c + k] * h->h_intr[9 * c + k];
-        }
-        if (h->pts_free) for (double v : h->h_points) { xs2 += v * v; fs2 += v * v; }
-        if (L.nbad > 0) { out.ok = false; return out; }
-        // damped reduced system on the host
-        bool solved = true;
-        if (ns > 0) {
-            std::memcpy(h->Swork.data(), L.S, sizeof(double) * (size_t)ns * ns);
-            for (int i = 0; i < ns; ++i) {
-                const double s2 = h->s2_shared[i];
-                double c = s2 * L.diagU[i];
-                c = std::min(std::max(c, d.min_diag), d.max_diag);
-                h->Ds[i] = c * d.inv_radius / s2 + d.mu;
-                h->Swork[(size_t)i * ns + i] += h->Ds[i];
-                h->rhs[i] = -L.gred[i];
-            }
-            if (want_S) std::memcpy(want_S, h->Swork.data(), sizeof(double) * (size_t)ns * ns);
-            solved = cvx::host_cholesky_solve(ns, h->Swork.data(), h->rhs.data());
-            if (solved) for (int i = 0; i < ns; ++i) solved = solved && std::isfinite(h->rhs[i]);
-        }
-        if (!solved) { out.ok = false; return out; }
-        for (int i = 0; i < ns; ++i) h->delta_s[i] = h->rhs[i];
-        // candidate shared parameters, embedded step per camera
-        h->h_intr_cand = h->h_intr; h->h_points_cand = h->h_points;
-        double ms = 0, ss2 = 0;
-        for (int i = 0; i < ns; ++i) {
-            const double ds = h->delta_s[i];
-            *shared_ptr_of(h, h->h_intr_cand, h->h_points_cand, i) += ds;
-            ms += ds * (h->Ds[i] * ds - L.gs[i]);
-            ss2 += ds * ds;
-        }
-        const int ncam = h->C * h->ncf;
-        std::memset(h->h_ds_emb, 0, sizeof(double) * (size_t)h->C * h->ZC);
-        for (int c = 0; c < h->C; ++c) {
-            double *e = h->h_ds_emb + (size_t)c * h->ZC;
-            if (h->pts_free) for (int q = 0; q < 3 * h->P; ++q) e[q] = h->delta_s[ncam + q];
-            for (int k = 0; k < h->ncf; ++k) {
-                const int kk = (h->fix_k3 && k >= 6) ? k + 1 : k;
-                e[h->camcol0 + kk] = h->delta_s[c * h->ncf + k];
-            }
-            e[h->ycol] = 1.0;
-        }
-        const int nxt = 1 - h->cur;
-        int st = upload_candidate(nxt);
-        if (st) { out.status = st; return out; }
-        ph_begin(h, PH_BACKSUBST);
-        if (h->V > 0) {
-            hipLaunchKernelGGL(k_backsubst, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, h->d_Z, h->d_Linv, h->d_Dv,
-                               h->d_gv, h->d_ds_emb, h->d_cam_of_view, h->d_poses[h->cur], h->d_poses[nxt],
-                               keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V, h->ZC);
-            if (hipGetLastError() != hipSuccess) { out.status = CVX_ERR_HIP; return out; }
-        }
-        ph_end(h, PH_BACKSUBST);
-        st = candidate_cost(nxt);
-        if (st) { out.status = st; return out; }
-        out.cand_cost = 0.5 * h->h_E2[0];
-        out.model_change = 0.5 * (h->h_E2[1] + ms);
-        out.step_norm2 = h->h_E2[2] + ss2;
-        out.x_norm2 = h->h_E2[3] + xs2;
-        out.free_norm2 = h->h_E2[3] + fs2;
+        if (R[12] > 0 || R[8] > 0) { out.ok = false; return out; }
+        out.cand_cost = 0.5 * R[0];
+        out.model_change = 0.5 * (R[1] + R[4]);
+        out.step_norm2 = R[2] + R[5];
+        out.x_norm2 = R[3] + R[6];
+        out.free_norm2 = R[3] + R[7];
         out.ok = std::isfinite(out.model_change) && std::isfinite(out.step_norm2);
         return out;
     }
 
     int accept() override {
         h->cur = 1 - h->cur;
-        h->h_intr = h->h_intr_cand;
-        h->h_points = h->h_points_cand;
         return CVX_OK;
     }
-
-    double *want_S = nullptr;
 
 private:
-    int upload_candidate(int nxt) {
-        CVX_HIP(hipMemcpyAsync(h->d_ds_emb, h->h_ds_emb, sizeof(double) * (size_t)h->C * h->ZC, hipMemcpyHostToDevice, h->stream));
-        CVX_HIP(hipMemcpyAsync(h->d_intr[nxt], h->h_intr_cand.data(), sizeof(double) * 9 * h->C, hipMemcpyHostToDevice, h->stream));
-        CVX_HIP(hipMemcpyAsync(h->d_points[nxt], h->h_points_cand.data(), sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
-        return CVX_OK;
-    }
-    int candidate_cost(int nxt) {
-        int st = launch_pose_prepare(h, h->d_poses[nxt]);
+    // the whole linear step on the device: linearise, damp + factor + solve the reduced system, form the
+    // candidate, back-substitute the poses, evaluate the candidate; one 16-double copy comes back
+    int run_step(const cvx_damping &d) {
+        int st = linearize(h, d, false, false);
+        if (st) return st;
+        const int ns = h->ns, nxt = 1 - h->cur;
+        ph_begin(h, PH_SOLVE);
+        CVX_HIP(hipMemsetAsync(h->d_fail, 0, sizeof(int), h->stream));
+        if (ns > 0) {
+            cvxs::DampArgs da;
+            da.E = h->d_E; da.s2 = h->d_s2sh; da.n = ns; da.npad = h->npad;
+            da.inv_radius = d.inv_radius; da.mu = d.mu; da.min_diag = d.min_diag; da.max_diag = d.max_diag;
+            da.A = h->d_A; da.Ds = h->d_Ds;
+            const long long tot = (long long)h->npad * h->npad;
+            hipLaunchKernelGGL(cvxs::k_damp_prepare, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, da);
+            if (want_S) {
+                h->h_A.resize((size_t)tot);
+                CVX_HIP(hipMemcpyAsync(h->h_A.data(), h->d_A, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            }
+            for (int k = 0; k < h->nT; ++k) {
+                const int ntr = h->nT - 1 - k;
+                const int blocks = std::max(1, ntr * (ntr + 1) / 2);
+                hipLaunchKernelGGL(cvxs::k_chol_step, dim3(blocks), dim3(256), 0, h->stream, h->d_A, h->d_L, h->npad, ns, k,
+                                   h->nT, h->d_fail);
+            }
+            CVX_HIP(hipGetLastError());
+        }
+        {
+            cvxs::FinishArgs f;
+            f.L = h->d_L; f.ld = h->npad; f.n = ns; f.npad = h->npad;
+            f.E = h->d_E; f.E_scal = (long long)h->E_scal; f.nranks = h->nranks; f.Ds = h->d_Ds; f.fail = h->d_fail;
+            f.C = h->C; f.P = h->P; f.ncf = h->ncf; f.fix_k3 = h->fix_k3; f.cam_free = h->cam_free; f.pts_free = h->pts_free;
+            f.ZC = h->ZC; f.camcol0 = h->camcol0; f.ycol = h->ycol;
+            f.intr = h->d_intr[h->cur]; f.points = h->d_points[h->cur];
+            f.intr_cand = h->d_intr[nxt]; f.points_cand = h->d_points[nxt];
+            f.ds_emb = h->d_ds_emb; f.delta_s = h->d_delta_s; f.R = h->d_E2;
+            hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(256), h->fin_lds, h->stream, f);
+            CVX_HIP(hipGetLastError());
+        }
+        ph_end(h, PH_SOLVE);
+        ph_begin(h, PH_BACKSUBST);
+        if (h->V > 0) {
+            hipLaunchKernelGGL(k_backsubst, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, h->d_Z, h->d_Linv, h->d_Dv,
+                               h->d_gv, h->d_ds_emb, h->d_cam_of_view, h->d_poses[h->cur], h->d_poses[nxt],
+                               keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V, h->ZC);
+            CVX_HIP(hipGetLastError());
+        }
+        ph_end(h, PH_BACKSUBST);
+        st = launch_pose_prepare(h, h->d_poses[nxt]);
         if (st) return st;
         ph_begin(h, PH_COST);
         hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
@@ -394,7 +367,7 @@ private:
         if (h->nranks > 1 && h->xfn && h->xdev) {
             if (h->xfn(h->xctx, h->d_E2, 4, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
         }
-        CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         CVX_HIP(hipStreamSynchronize(h->stream));
         ph_collect(h);
         if (h->nranks > 1 && h->xfn && !h->xdev) {
@@ -403,6 +376,7 @@ private:
         return CVX_OK;
     }
 };
+
 
 int alloc_exchange(cvx_calib *h) {
     if (h->d_E) { (void)hipFree(h->d_E); h->d_E = nullptr; }
@@ -529,7 +503,15 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(dev_upload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
     CVX_TRY(dev_upload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
     CVX_TRY(dev_upload(&h->d_chk_row0, chk_row0.data(), chk_row0.size(), s));
-    CVX_TRY(dev_upload(&h->d_chk_cam, chk_cam.data(), chk_cam.size(), s));
+    {
+        std::vector<int> clist(h->n_chunks), clist_off(C + 1, 0);
+        for (int q = 0; q < h->n_chunks; ++q) clist_off[chk_cam[q] + 1]++;
+        for (int c = 0; c < C; ++c) clist_off[c + 1] += clist_off[c];
+        std::vector<int> pos(clist_off.begin(), clist_off.end() - 1);
+        for (int q = 0; q < h->n_chunks; ++q) clist[pos[chk_cam[q]]++] = q;
+        CVX_TRY(dev_upload(&h->d_clist, clist.data(), clist.size(), s));
+        CVX_TRY(dev_upload(&h->d_clist_off, clist_off.data(), clist_off.size(), s));
+    }
     CVX_TRY(dev_upload(&h->d_glist, glist.data(), glist.size(), s));
     CVX_TRY(dev_upload(&h->d_glist_off, glist_off.data(), glist_off.size(), s));
     for (int k = 0; k < 2; ++k) {
@@ -554,8 +536,9 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(dev_alloc(&h->d_slab_cam, (size_t)h->n_groups * 256));
     CVX_TRY(dev_alloc(&h->d_grp_scal, (size_t)h->n_groups * 4));
     CVX_TRY(dev_alloc(&h->d_slab_tile, (size_t)h->n_chunks * h->ntp * ZTILE * ZTILE));
-    CVX_TRY(dev_alloc(&h->d_Ucx, (size_t)C * P * 27));
-    CVX_TRY(dev_alloc(&h->d_Uxx, (size_t)P * 9));
+    CVX_TRY(dev_alloc(&h->d_Tpt, (size_t)C * P * PT_ACC));
+    CVX_HIP(hipMemsetAsync(h->d_Tpt, 0, (size_t)C * P * PT_ACC * sizeof(double), s));
+    CVX_TRY(dev_alloc(&h->d_Tt, (size_t)C * h->ntp * ZTILE * ZTILE));
     CVX_TRY(dev_alloc(&h->d_Gcam, (size_t)C * 256));
     CVX_TRY(alloc_exchange(h));
     CVX_TRY(dev_alloc(&h->d_ds_emb, (size_t)C * h->ZC));
@@ -564,14 +547,24 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(dev_alloc(&h->d_out_view, 3 * (size_t)V));
     h->n_cost_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (h->N + 255) / 256));
     CVX_TRY(dev_alloc(&h->d_cost_partial, (size_t)h->n_cost_blocks));
-    CVX_TRY(dev_alloc(&h->d_E2, 8));
-    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 8 * sizeof(double), hipHostMallocDefault));
+    CVX_TRY(dev_alloc(&h->d_E2, 16));
+    CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
+    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 16 * sizeof(double), hipHostMallocDefault));
+    // damped reduced solve: (ns + 1) rows (the right-hand side rides as row ns), padded to 32-tiles
+    h->nT = (h->ns + 1 + cvxs::TB - 1) / cvxs::TB;
+    h->npad = h->nT * cvxs::TB;
+    CVX_TRY(dev_alloc(&h->d_A, (size_t)h->npad * h->npad));
+    CVX_TRY(dev_alloc(&h->d_L, (size_t)h->npad * h->npad));
+    CVX_HIP(hipMemsetAsync(h->d_L, 0, (size_t)h->npad * h->npad * sizeof(double), s));
+    CVX_TRY(dev_alloc(&h->d_s2sh, (size_t)std::max(1, h->ns)));
+    CVX_TRY(dev_alloc(&h->d_Ds, (size_t)std::max(1, h->ns)));
+    CVX_HIP(hipMemsetAsync(h->d_Ds, 0, (size_t)std::max(1, h->ns) * sizeof(double), s));
+    CVX_TRY(dev_alloc(&h->d_delta_s, (size_t)std::max(1, h->ns)));
+    CVX_TRY(dev_alloc(&h->d_fail, 1));
+    h->fin_lds = sizeof(double) * ((size_t)h->npad + cvxs::TB * (cvxs::TB + 1) + 8 * cvxs::TB + 256);
 #undef CVX_TRY
-    h->h_intr.assign(9 * (size_t)C, 0.0); h->h_points.assign(3 * (size_t)P, 0.0);
-    h->h_intr_cand = h->h_intr; h->h_points_cand = h->h_points;
-    const size_t nsz = std::max(1, h->ns);
-    h->s2_shared.assign(nsz, 1.0); h->Ds.assign(nsz, 0.0); h->delta_s.assign(nsz, 0.0);
-    h->Swork.assign(nsz * nsz, 0.0); h->rhs.assign(nsz, 0.0);
+    h->s2_shared.assign((size_t)std::max(1, h->ns), 1.0);
+    CVX_HIP(hipMemcpyAsync(h->d_s2sh, h->s2_shared.data(), sizeof(double) * std::max(1, h->ns), hipMemcpyHostToDevice, s));
     for (int i = 0; i < PH_COUNT; ++i) {
         CVX_HIP(hipEventCreate(&h->ev[i][0]));
         CVX_HIP(hipEventCreate(&h->ev[i][1]));
@@ -587,8 +580,6 @@ extern "C" void cvx_calib_destroy(cvx_calib *h) { delete h; }
 extern "C" int cvx_calib_set_params(cvx_calib *h, const double *intr, const double *poses, const double *points) {
     if (!h || !intr || !points || (h->V > 0 && !poses)) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
-    h->h_intr.assign(intr, intr + 9 * (size_t)h->C);
-    h->h_points.assign(points, points + 3 * (size_t)h->P);
     const int c = h->cur;
     CVX_HIP(hipMemcpyAsync(h->d_intr[c], intr, sizeof(double) * 9 * h->C, hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_points[c], points, sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
@@ -600,12 +591,12 @@ extern "C" int cvx_calib_set_params(cvx_calib *h, const double *intr, const doub
 extern "C" int cvx_calib_get_params(cvx_calib *h, double *intr, double *poses, double *points) {
     if (!h) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
-    if (intr) std::memcpy(intr, h->h_intr.data(), sizeof(double) * 9 * h->C);
-    if (points) std::memcpy(points, h->h_points.data(), sizeof(double) * 3 * h->P);
-    if (poses && h->V) {
-        CVX_HIP(hipMemcpyAsync(poses, h->d_poses[h->cur], sizeof(double) * 6 * (size_t)h->V, hipMemcpyDeviceToHost, h->stream));
-        CVX_HIP(hipStreamSynchronize(h->stream));
-    }
+    const int c = h->cur;
+    if (intr) CVX_HIP(hipMemcpyAsync(intr, h->d_intr[c], sizeof(double) * 9 * h->C, hipMemcpyDeviceToHost, h->stream));
+    if (points) CVX_HIP(hipMemcpyAsync(points, h->d_points[c], sizeof(double) * 3 * h->P, hipMemcpyDeviceToHost, h->stream));
+    if (poses && h->V)
+        CVX_HIP(hipMemcpyAsync(poses, h->d_poses[c], sizeof(double) * 6 * (size_t)h->V, hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
     return CVX_OK;
 }
 
@@ -686,14 +677,18 @@ extern "C" int cvx_calib_linear_step(cvx_calib *h, const cvx_damping *d, double 
     ev.want_S = S;
     cvx::StepInfo s = ev.try_step(*d, -1.0, false);
     if (s.status) return s.status;
+    const int ns = h->ns;
     if (cost) *cost = s.cost;
-    if (gred) std::memcpy(gred, h->h_E + (size_t)h->ns * h->ns, sizeof(double) * h->ns);
-    if (!s.ok) return CVX_ERR_NUMERIC;
-    if (delta_shared) std::memcpy(delta_shared, h->delta_s.data(), sizeof(double) * h->ns);
-    if (delta_poses && h->V) {
+    if (gred && ns) CVX_HIP(hipMemcpyAsync(gred, h->d_E + (size_t)ns * ns, sizeof(double) * ns, hipMemcpyDeviceToHost, h->stream));
+    if (S)      // the damped matrix as it entered the factorisation (lower triangle mirrored)
+        for (int i = 0; i < ns; ++i)
+            for (int j = 0; j < ns; ++j) S[(size_t)i * ns + j] = h->h_A[(size_t)std::max(i, j) * h->npad + std::min(i, j)];
+    if (delta_shared && ns)
+        CVX_HIP(hipMemcpyAsync(delta_shared, h->d_delta_s, sizeof(double) * ns, hipMemcpyDeviceToHost, h->stream));
+    if (delta_poses && h->V)
         CVX_HIP(hipMemcpyAsync(delta_poses, h->d_dposes, sizeof(double) * 6 * (size_t)h->V, hipMemcpyDeviceToHost, h->stream));
-        CVX_HIP(hipStreamSynchronize(h->stream));
-    }
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    if (!s.ok) return CVX_ERR_NUMERIC;
     if (cand_cost) *cand_cost = s.cand_cost;
     if (model_change) *model_change = s.model_change;
     return CVX_OK;

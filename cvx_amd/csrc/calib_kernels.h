@@ -539,57 +539,56 @@ __global__ void __launch_bounds__(256) k_schur_syrk(K3Args a) {
 }
 
 // -----------------------------------------------------------------------------------------
-// U-reduce: sum the per-group slabs in fixed order.
-//   Ucx[C][P][27], Uxx[P][9] (6 Hessian + 3 gradient), Gcam[C][256], scal[4]
+// Slab reductions, fixed order.  k_group_sum: dst[c][e] = sum over the slabs listed for camera c
+// of src[slab * stride + e]; a block is 64 consecutive outputs x 4 slices of the list, so every
+// load is a coalesced 512 B row segment and the four partial sums are combined as (0+1)+(2+3).
+// Used for the per-point accumulators (slab_pt -> Tpt[C][P*36]), the per-camera Gram tiles
+// (slab_cam -> Gcam[C][256]) and the Schur tiles (slab_tile -> Tt[C][ntp*48*48]).
 // -----------------------------------------------------------------------------------------
-struct URArgs {
-    const double *slab_pt, *slab_cam, *grp_scal;
-    const int *glist, *glist_off;   // groups of each camera: glist[glist_off[c] .. glist_off[c+1])
-    int n_groups, C, P, cam_free, pts_free;
-    double *Ucx, *Uxx, *Gcam;
-    double *out_sum, *out_bad, *out_gmax, *out_dmax;   // sum r^2, bad pose blocks, max |g_pose|, max diag V
-};
+__global__ void __launch_bounds__(256) k_group_sum(const double *__restrict__ src, size_t stride, int n_out,
+                                                   const int *__restrict__ list, const int *__restrict__ list_off,
+                                                   double *__restrict__ dst) {
+    __shared__ double part[4][64];
+    const int c = blockIdx.y, lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int q0 = list_off[c], q1 = list_off[c + 1];
+    const int per = (q1 - q0 + 3) >> 2;
+    const int a0 = q0 + sl * per, a1 = min(q1, a0 + per);
+    double s = 0.0;
+    if (e < n_out)
+        for (int q = a0; q < a1; ++q) s += src[(size_t)list[q] * stride + e];
+    part[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && e < n_out) dst[(size_t)c * n_out + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
 
-__global__ void __launch_bounds__(256) k_ureduce(URArgs a) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long n_ucx = (a.cam_free && a.pts_free) ? (long long)a.C * a.P * 27 : 0;
-    const long long n_uxx = a.pts_free ? (long long)a.P * 9 : 0;
-    const long long n_gcam = (long long)a.C * 256;
-    if (t < n_ucx) {
-        const int c = (int)(t / (a.P * 27)), rem = (int)(t % (a.P * 27));
-        const int p = rem / 27, k = rem % 27;
-        double s = 0.0;
-        for (int q = a.glist_off[c]; q < a.glist_off[c + 1]; ++q)
-            s += a.slab_pt[((size_t)a.glist[q] * a.P + p) * PT_ACC + k];
-        a.Ucx[t] = s;
-        return;
+// scalars of one linearisation (single block): sum r^2 (entry 255 of every camera's Gram tile),
+// number of pose blocks that failed to factor, max |g_pose|, max diag V
+__global__ void __launch_bounds__(256) k_lin_scalars(const double *__restrict__ Gcam, int C,
+                                                     const double *__restrict__ grp_scal, int n_groups,
+                                                     double *out_sum, double *out_bad, double *out_gmax,
+                                                     double *out_dmax) {
+    __shared__ double sh[3][256];
+    double gm = 0.0, dm = 0.0, nb = 0.0;
+    for (int q = threadIdx.x; q < n_groups; q += 256) {
+        gm = fmax(gm, grp_scal[4 * q]);
+        dm = fmax(dm, grp_scal[4 * q + 1]);
+        nb += grp_scal[4 * q + 2];
     }
-    long long u = t - n_ucx;
-    if (u < n_uxx) {
-        const int p = (int)(u / 9), k = (int)(u % 9);
-        double s = 0.0;
-        for (int q = 0; q < a.n_groups; ++q) s += a.slab_pt[((size_t)q * a.P + p) * PT_ACC + 27 + k];
-        a.Uxx[u] = s;
-        return;
-    }
-    u -= n_uxx;
-    if (u < n_gcam) {
-        const int c = (int)(u / 256), e = (int)(u % 256);
-        double s = 0.0;
-        for (int q = a.glist_off[c]; q < a.glist_off[c + 1]; ++q) s += a.slab_cam[(size_t)a.glist[q] * 256 + e];
-        a.Gcam[u] = s;
-        return;
-    }
-    u -= n_gcam;
-    if (u == 0) {
-        double s = 0.0, gm = 0.0, dm = 0.0, nb = 0.0;
-        for (int q = 0; q < a.n_groups; ++q) {
-            s += a.slab_cam[(size_t)q * 256 + 255];
-            gm = fmax(gm, a.grp_scal[4 * q]);
-            dm = fmax(dm, a.grp_scal[4 * q + 1]);
-            nb += a.grp_scal[4 * q + 2];
+    sh[0][threadIdx.x] = gm; sh[1][threadIdx.x] = dm; sh[2][threadIdx.x] = nb;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            sh[0][threadIdx.x] = fmax(sh[0][threadIdx.x], sh[0][threadIdx.x + off]);
+            sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + off]);
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + off];
         }
-        *a.out_sum = s; *a.out_bad = nb; *a.out_gmax = gm; *a.out_dmax = dm;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int c = 0; c < C; ++c) s += Gcam[(size_t)c * 256 + 255];
+        *out_sum = s; *out_bad = sh[2][0]; *out_gmax = sh[0][0]; *out_dmax = sh[1][0];
     }
 }
 
@@ -597,11 +596,12 @@ __global__ void __launch_bounds__(256) k_ureduce(URArgs a) {
 // Assemble the exchange buffer E (one thread per entry):
 //   E = [ S = U - Z^T Z (ns*ns) | gred (ns) | gs (ns) | diagU (ns) | scalars... ]
 // shared-parameter order (API): free intrinsics of camera 0, 1, ..., then points xyz.
+// Inputs are the per-camera sums made by k_group_sum: Tpt[C][P][36] (Ucx 27 | Uxx 6 | gx 3),
+// Gcam[C][256], Tt[C][ntp][48*48] (null when the Schur term is absent).
 // -----------------------------------------------------------------------------------------
 struct AsmArgs {
-    const double *slab, *Ucx, *Uxx, *Gcam;
-    const int *chk_cam;
-    int ns, C, P, ncf, fix_k3, pts_free, ZC, camcol0, ycol, nt, ntp, n_chunks;
+    const double *Tt, *Tpt, *Gcam;
+    int ns, C, P, ncf, fix_k3, pts_free, ZC, camcol0, ycol, nt, ntp;
     double *E;
 };
 
@@ -624,11 +624,22 @@ __device__ __forceinline__ SharedIdx shared_index(const AsmArgs &a, int i) {
     return s;
 }
 
-__device__ __forceinline__ double tile_value(const AsmArgs &a, int ch, int zi, int zj) {
+// offset of Z^T Z entry (zi, zj) inside one camera's tile block
+__device__ __forceinline__ size_t tile_offset(const AsmArgs &a, int zi, int zj) {
     int ti = zi / ZTILE, tj = zj / ZTILE;
     if (ti > tj) { int t = ti; ti = tj; tj = t; t = zi; zi = zj; zj = t; }
     const int tp = ti * a.nt - ti * (ti - 1) / 2 + (tj - ti);
-    return a.slab[((size_t)ch * a.ntp + tp) * (ZTILE * ZTILE) + (zi % ZTILE) * ZTILE + (zj % ZTILE)];
+    return (size_t)tp * (ZTILE * ZTILE) + (zi % ZTILE) * ZTILE + (zj % ZTILE);
+}
+
+// sum of the cameras' tile entries: all cameras (cam < 0) or one
+__device__ __forceinline__ double tile_sum(const AsmArgs &a, int cam, int zi, int zj) {
+    if (!a.Tt) return 0.0;
+    const size_t off = tile_offset(a, zi, zj), cs = (size_t)a.ntp * (ZTILE * ZTILE);
+    if (cam >= 0) return a.Tt[cam * cs + off];
+    double z = 0.0;
+    for (int c = 0; c < a.C; ++c) z += a.Tt[c * cs + off];
+    return z;
 }
 
 __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
@@ -639,42 +650,39 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
     if (t < nn) {
         const int i = (int)(t / a.ns), j = (int)(t % a.ns);
         const SharedIdx si = shared_index(a, i), sj = shared_index(a, j);
-        double u = 0.0;
+        double u = 0.0, z = 0.0;
         if (si.is_cam && sj.is_cam) {
-            if (si.c == sj.c) u = a.Gcam[(size_t)si.c * 256 + (6 + si.kk) * 16 + 6 + sj.kk];
-        } else if (si.is_cam) {
-            u = a.Ucx[((size_t)si.c * a.P + sj.p) * 27 + si.kk * 3 + sj.b];
-        } else if (sj.is_cam) {
-            u = a.Ucx[((size_t)sj.c * a.P + si.p) * 27 + sj.kk * 3 + si.b];
-        } else if (si.p == sj.p) {
-            u = a.Uxx[si.p * 9 + sym6[si.b * 3 + sj.b]];
-        }
-        double z = 0.0;
-        const bool cross_cam = si.is_cam && sj.is_cam && si.c != sj.c;
-        if (!cross_cam)
-            for (int ch = 0; ch < a.n_chunks; ++ch) {
-                const int cc = a.chk_cam[ch];
-                if (si.is_cam && cc != si.c) continue;
-                if (sj.is_cam && cc != sj.c) continue;
-                z += tile_value(a, ch, si.zcol, sj.zcol);
+            if (si.c == sj.c) {
+                u = a.Gcam[(size_t)si.c * 256 + (6 + si.kk) * 16 + 6 + sj.kk];
+                z = tile_sum(a, si.c, si.zcol, sj.zcol);
             }
+        } else if (si.is_cam) {
+            u = a.Tpt[((size_t)si.c * a.P + sj.p) * PT_ACC + si.kk * 3 + sj.b];
+            z = tile_sum(a, si.c, si.zcol, sj.zcol);
+        } else if (sj.is_cam) {
+            u = a.Tpt[((size_t)sj.c * a.P + si.p) * PT_ACC + sj.kk * 3 + si.b];
+            z = tile_sum(a, sj.c, si.zcol, sj.zcol);
+        } else {
+            if (si.p == sj.p)
+                for (int c = 0; c < a.C; ++c) u += a.Tpt[((size_t)c * a.P + si.p) * PT_ACC + 27 + sym6[si.b * 3 + sj.b]];
+            z = tile_sum(a, -1, si.zcol, sj.zcol);
+        }
         a.E[t] = u - z;
     } else {
         const int i = (int)(t - nn);
         const SharedIdx si = shared_index(a, i);
-        double g, d;
+        double g = 0.0, d = 0.0;
         if (si.is_cam) {
             g = a.Gcam[(size_t)si.c * 256 + (6 + si.kk) * 16 + 15];
             d = a.Gcam[(size_t)si.c * 256 + (6 + si.kk) * 16 + 6 + si.kk];
         } else {
-            g = a.Uxx[si.p * 9 + 6 + si.b];
-            d = a.Uxx[si.p * 9 + sym6[si.b * 4]];
+            for (int c = 0; c < a.C; ++c) {
+                const double *pa = a.Tpt + ((size_t)c * a.P + si.p) * PT_ACC;
+                g += pa[33 + si.b];
+                d += pa[27 + sym6[si.b * 4]];
+            }
         }
-        double z = 0.0;
-        for (int ch = 0; ch < a.n_chunks; ++ch) {
-            if (si.is_cam && a.chk_cam[ch] != si.c) continue;
-            z += tile_value(a, ch, si.zcol, a.ycol);
-        }
+        const double z = tile_sum(a, si.is_cam ? si.c : -1, si.zcol, a.ycol);
         a.E[nn + i] = g - z;
         a.E[nn + a.ns + i] = g;
         a.E[nn + 2 * a.ns + i] = d;

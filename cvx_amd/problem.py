@@ -95,7 +95,7 @@ class Calib:
     def phase_times(self):
         ms = np.zeros(16)
         check(lib().cvx_calib_phase_times(self.h, pd(ms)), "phase_times")
-        names = ["normal_eq", "schur", "assemble", "backsubst", "cost"]
+        names = ["normal_eq", "schur", "assemble", "backsubst", "cost", "solve"]
         return {n: (ms[i], int(ms[8 + i])) for i, n in enumerate(names)}
 
     def geometry(self):

@@ -183,8 +183,8 @@ double cvx_calib_refine_return(double total_cost, int64_t n_obs_total);
 
 /* Per-phase device time, measured with hipEvents on the handle's stream while timing is enabled.
  * ms[0..7]: accumulated milliseconds of [0] normal-equation kernel, [1] Schur contraction,
- * [2] reduce + assemble, [3] back-substitution, [4] candidate cost; ms[8..15]: launches counted
- * per phase.  cvx_calib_enable_timing resets the accumulators. */
+ * [2] reduce + assemble, [3] back-substitution, [4] candidate cost, [5] damped reduced solve
+ * (damp, tiled Cholesky, finish); ms[8..15]: launches counted per phase.  cvx_calib_enable_timing resets the accumulators. */
 int cvx_calib_enable_timing(cvx_calib *h, int enable);
 int cvx_calib_phase_times(cvx_calib *h, double ms[16]);
 
