@@ -55,18 +55,27 @@ __global__ void __launch_bounds__(256) k_damp_prepare(DampArgs a) {
     a.A[t] = v;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+
 // -----------------------------------------------------------------------------------------
-// One tile column k of the factorisation.  Block b owns trailing tile (ti, tj), k < tj <= ti:
-// it factors the diagonal tile A_kk (every block redundantly: 32 columns, one wave), solves its
-// two panel tiles L_ik = A_ik L_kk^-T, L_jk, and updates A_ij -= L_ik L_jk^T with MFMA.  Panel k of
-// A is only read in this launch; factor tiles are written to the separate array L (block 0 the
-// diagonal tile, the blocks with tj == k + 1 their L_ik), so no block reads what another writes.
+// One tile column k of the factorisation.  Block b owns trailing tile (ti, tj), k < tj <= ti.
+// Waves 0 and 1 each run the left-looking column loop over 64 rows: lanes 0..31 hold the rows of
+// the diagonal tile A_kk (factored redundantly by both waves and by every block: it is the serial
+// part either way), lanes 32..63 the rows of the panel tile A_ik (wave 0) or A_jk (wave 1) -- a
+// panel row obeys the same recurrence L[r][j] = (A[r][j] - sum_{m<j} L[r][m] L[j][m]) / L[j][j], so
+// the triangular solve rides along for free.  Then all four waves update A_ij -= L_ik L_jk^T with
+// MFMA.  Panel k of A is only read in this launch; factor tiles go to the separate array L (block
+// 0 the diagonal tile, the blocks with tj == k + 1 their L_ik): no block reads what another writes.
 // Rows with global index >= n (the right-hand-side row and the padding) take diagonal 1.
 // -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld, int n, int k, int nT, int *fail) {
-    __shared__ double D[TB][TB + 1];
-    __shared__ double Pi[TB][TB + 1], Pj[TB][TB + 1];
-    __shared__ double invd[TB];
+    __shared__ double D[2][TB][TB + 1];
+    __shared__ double P[2][TB][TB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntr = nT - 1 - k;
     int ti = -1, tj = -1;
@@ -75,83 +84,83 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
         while (rem > r) { rem -= r + 1; ++r; }
         ti = k + 1 + r; tj = k + 1 + rem;
     }
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int r = e >> 5, c = e & 31;
-        D[r][c] = A[(size_t)(k * TB + r) * ld + k * TB + c];
-        if (ti >= 0) {
-            Pi[r][c] = A[(size_t)(ti * TB + r) * ld + k * TB + c];
-            Pj[r][c] = A[(size_t)(tj * TB + r) * ld + k * TB + c];
+    // this wave's 16x16 block of A_ij, fetched now so the latency hides behind the factorisation
+    const int bi = wave >> 1, bj = wave & 1, kq = lane >> 4, cq = lane & 15;
+    double a_old[4] = {0.0, 0.0, 0.0, 0.0};
+    if (ti >= 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_old[q] = A[(size_t)(ti * TB + bi * 16 + kq + 4 * q) * ld + tj * TB + bj * 16 + cq];
+    }
+    {
+        double vd[4], vi[4], vj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+            vd[q] = A[(size_t)(k * TB + r) * ld + k * TB + c];
+            vi[q] = (ti >= 0) ? A[(size_t)(ti * TB + r) * ld + k * TB + c] : 0.0;
+            vj[q] = (ti >= 0) ? A[(size_t)(tj * TB + r) * ld + k * TB + c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, r = e >> 5, c = e & 31;
+            D[0][r][c] = vd[q]; D[1][r][c] = vd[q];
+            P[0][r][c] = vi[q]; P[1][r][c] = vj[q];
         }
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave < 2) {
         const int r = lane & 31;
+        const bool panel = lane >= 32;
+        double (*Dw)[TB + 1] = D[wave];
         double row[TB];
         bool bad = false;
 #pragma unroll
-        for (int c = 0; c < TB; ++c) row[c] = D[r][c];
+        for (int c = 0; c < TB; ++c) row[c] = panel ? P[wave][r][c] : Dw[r][c];
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
-            // left-looking column j: t = A[r][j] - sum_{m<j} L[r][m] L[j][m]
             double t0 = row[j], t1 = 0.0;
 #pragma unroll
             for (int m = 0; m < j; ++m) {
-                const double ljm = D[j][m];
-                if (m & 1) t1 += row[m] * ljm; else t0 -= row[m] * ljm;
+                const double ljm = Dw[j][m];
+                if (m & 1) t1 = fma(row[m], ljm, t1); else t0 = fma(-row[m], ljm, t0);
             }
             const double t = t0 - t1;
-            const double d = __shfl(t, j, 64);
+            const double d = readlane_f64(t, j);
             const bool special = (k * TB + j) >= n;
             bad = bad || (!special && !(d > 0.0 && d < 1.7e308));
-            const double l = special ? 1.0 : sqrt(d);
-            const double inv = 1.0 / l;
-            row[j] = (r == j) ? l : t * inv;
+            const double ri = special ? 1.0 : rsqrt(d);
+            const double val = (lane == j) ? (special ? 1.0 : d * ri) : t * ri;
+            row[j] = val;
             __builtin_amdgcn_wave_barrier();
-            D[r][j] = row[j];
-            if (r == j) invd[j] = inv;
+            if (!panel) Dw[r][j] = val;
             __builtin_amdgcn_wave_barrier();
         }
-        if (ti >= 0) {
-            // panel rows: lanes 0..31 solve a row of A_ik, lanes 32..63 a row of A_jk:  x L_kk^T = a
-            double (*Pm)[TB + 1] = (lane < 32) ? Pi : Pj;
-            double x[TB];
+        if (panel) {
 #pragma unroll
-            for (int c = 0; c < TB; ++c) x[c] = Pm[r][c];
-#pragma unroll
-            for (int c = 0; c < TB; ++c) {
-                x[c] *= invd[c];
-#pragma unroll
-                for (int m = c + 1; m < TB; ++m) x[m] -= x[c] * D[m][c];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int c = 0; c < TB; ++c) Pm[r][c] = x[c];
+            for (int c = 0; c < TB; ++c) P[wave][r][c] = row[c];
         }
-        if (__any(bad) && lane == 0) *fail = 1;
+        if (wave == 0 && __any(bad) && lane == 0) *fail = 1;
     }
     __syncthreads();
     if (blockIdx.x == 0)
         for (int e = tid; e < TB * TB; e += 256) {
             const int r = e >> 5, c = e & 31;
-            L[(size_t)(k * TB + r) * ld + k * TB + c] = (c <= r) ? D[r][c] : 0.0;
+            L[(size_t)(k * TB + r) * ld + k * TB + c] = (c <= r) ? D[0][r][c] : 0.0;
         }
     if (ti < 0) return;
     if (tj == k + 1)
         for (int e = tid; e < TB * TB; e += 256) {
             const int r = e >> 5, c = e & 31;
-            L[(size_t)(ti * TB + r) * ld + k * TB + c] = Pi[r][c];
+            L[(size_t)(ti * TB + r) * ld + k * TB + c] = P[0][r][c];
         }
     // A_ij -= L_ik L_jk^T: wave w owns the 16x16 block (w >> 1, w & 1)
-    const int bi = wave >> 1, bj = wave & 1, kq = lane >> 4, cq = lane & 15;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < TB / 4; ++ks)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pi[bi * 16 + cq][ks * 4 + kq], Pj[bj * 16 + cq][ks * 4 + kq], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0][bi * 16 + cq][ks * 4 + kq], P[1][bj * 16 + cq][ks * 4 + kq], acc, 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const size_t idx = (size_t)(ti * TB + bi * 16 + kq + 4 * q) * ld + tj * TB + bj * 16 + cq;
-        A[idx] = A[idx] - acc[q];
-    }
+    for (int q = 0; q < 4; ++q)
+        A[(size_t)(ti * TB + bi * 16 + kq + 4 * q) * ld + tj * TB + bj * 16 + cq] = a_old[q] - acc[q];
 }
 
 // -----------------------------------------------------------------------------------------
@@ -174,68 +183,100 @@ struct FinishArgs {
     int C, P, ncf, fix_k3, cam_free, pts_free, ZC, camcol0, ycol;
     const double *intr, *points;
     double *intr_cand, *points_cand, *ds_emb, *delta_s, *R;
+#ifdef CVX_STAMPS
+    long long *stamps;
+#endif
 };
 
-__device__ __forceinline__ double block_sum(double v, double *red, int tid) {
-    red[tid] = v;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
-    }
-    const double r = red[0];
-    __syncthreads();
-    return r;
+// block reductions of the finish kernel: wave butterflies, then four partials through LDS
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
-
-__device__ __forceinline__ double block_max(double v, double *red, int tid) {
-    red[tid] = v;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
-        __syncthreads();
-    }
-    const double r = red[0];
-    __syncthreads();
-    return r;
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
 }
 
 __global__ void __launch_bounds__(256) k_solve_finish(FinishArgs a) {
     extern __shared__ double sm[];
     double *xs = sm;                       // [npad]
     double *tile = xs + a.npad;            // [32][33]
-    double *part = tile + TB * (TB + 1);   // [8][32]
-    double *red = part + 8 * TB;           // [256]
+    double *red = tile + TB * (TB + 1);    // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n, ld = a.ld;
     for (int i = tid; i < a.npad; i += 256) xs[i] = (i < n) ? a.L[(size_t)n * ld + i] : 0.0;
-    __syncthreads();
+#ifdef CVX_STAMPS
+    int sti = 0;
+#define STAMP() do { if (tid == 0) a.stamps[sti++] = wall_clock64(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
     const int nTn = (n + TB - 1) / TB;
-    for (int kt = nTn - 1; kt >= 0; --kt) {
-        for (int e = tid; e < TB * TB; e += 256) {
-            const int r = e >> 5, c = e & 31;
-            tile[r * (TB + 1) + c] = a.L[(size_t)(kt * TB + r) * ld + kt * TB + c];
+    // right-looking back substitution L^T x = y, one 32-tile at a time from the bottom; the next
+    // diagonal tile is fetched into registers while the current one is being solved
+    double tnext[4] = {0.0, 0.0, 0.0, 0.0};
+    if (nTn > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            tnext[q] = a.L[(size_t)((nTn - 1) * TB + (e >> 5)) * ld + (nTn - 1) * TB + (e & 31)];
         }
-        {
-            const int g = tid >> 5, c = tid & 31;
-            double s = 0.0;
-            for (int r = (kt + 1) * TB + g; r < n; r += 8) s += a.L[(size_t)r * ld + kt * TB + c] * xs[r];
-            part[g * TB + c] = s;
+    }
+    __syncthreads();
+    for (int kt = nTn - 1; kt >= 0; --kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            tile[(e >> 5) * (TB + 1) + (e & 31)] = tnext[q];
+        }
+        if (kt > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q;
+                tnext[q] = a.L[(size_t)((kt - 1) * TB + (e >> 5)) * ld + (kt - 1) * TB + (e & 31)];
+            }
         }
         __syncthreads();
+        STAMP();
         if (wave == 0) {
             const int m = lane & 31;
-            double rhs = xs[kt * TB + m] - (((part[m] + part[TB + m]) + (part[2 * TB + m] + part[3 * TB + m])) +
-                                            ((part[4 * TB + m] + part[5 * TB + m]) + (part[6 * TB + m] + part[7 * TB + m])));
+            const double invm = 1.0 / tile[m * (TB + 1) + m];
+            double rhs = xs[kt * TB + m] * invm;        // lane m carries rhs_m / L_mm
+            // w[c] = L[c][m] / L_mm: x_c = rhs(lane c) once every c' > c has been eliminated
+            double w[TB];
 #pragma unroll
-            for (int c = TB - 1; c >= 0; --c) {
-                const double xc = __shfl(rhs, c, 64) / tile[c * (TB + 1) + c];
-                if (m == c) rhs = xc;
-                else if (m < c) rhs -= tile[c * (TB + 1) + m] * xc;
+            for (int c = 0; c < TB; ++c) w[c] = tile[c * (TB + 1) + m] * invm;
+#pragma unroll
+            for (int c = TB - 1; c > 0; --c) {
+                const double xc = readlane_f64(rhs, c);
+                if (m < c) rhs = fma(-w[c], xc, rhs);
             }
             if (lane < 32) xs[kt * TB + m] = rhs;
         }
         __syncthreads();
+        STAMP();
+        // xs[j] -= sum_c L[kt*32 + c][j] x[kt*32 + c] for every column j left of this tile
+        for (int j = tid; j < kt * TB; j += 256) {
+            const double *Lc = a.L + (size_t)(kt * TB) * ld + j;
+            double lv[TB];
+#pragma unroll
+            for (int c = 0; c < TB; ++c) lv[c] = Lc[(size_t)c * ld];     // all 32 loads in flight together
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int c = 0; c < TB; c += 4) {
+                s0 += lv[c] * xs[kt * TB + c];
+                s1 += lv[c + 1] * xs[kt * TB + c + 1];
+                s2 += lv[c + 2] * xs[kt * TB + c + 2];
+                s3 += lv[c + 3] * xs[kt * TB + c + 3];
+            }
+            xs[j] -= (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        STAMP();
     }
     // ---- the step and its scalars ----
     const double *gs = a.E + (size_t)n * n + n, *dU = gs + n;
@@ -279,13 +320,22 @@ __global__ void __launch_bounds__(256) k_solve_finish(FinishArgs a) {
         } else if (col == a.ycol) v = 1.0;
         a.ds_emb[e] = v;
     }
-    ms = block_sum(ms, red, tid);
-    ss2 = block_sum(ss2, red, tid);
-    xs2 = block_sum(xs2, red, tid);
-    fs2 = block_sum(fs2, red, tid);
-    gm = block_max(gm, red, tid);
-    dm = block_max(dm, red, tid);
-    bad = block_max(bad, red, tid);
+    ms = wave_sum(ms); ss2 = wave_sum(ss2); xs2 = wave_sum(xs2); fs2 = wave_sum(fs2);
+    gm = wave_max(gm); dm = wave_max(dm); bad = wave_max(bad);
+    if (lane == 0) {
+        double *rw = red + 8 * wave;
+        rw[0] = ms; rw[1] = ss2; rw[2] = xs2; rw[3] = fs2; rw[4] = gm; rw[5] = dm; rw[6] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ms = (red[0] + red[8]) + (red[16] + red[24]);
+        ss2 = (red[1] + red[9]) + (red[17] + red[25]);
+        xs2 = (red[2] + red[10]) + (red[18] + red[26]);
+        fs2 = (red[3] + red[11]) + (red[19] + red[27]);
+        gm = fmax(fmax(red[4], red[12]), fmax(red[20], red[28]));
+        dm = fmax(fmax(red[5], red[13]), fmax(red[21], red[29]));
+        bad = fmax(fmax(red[6], red[14]), fmax(red[22], red[30]));
+    }
     if (tid == 0) {
         const double *scal = a.E + a.E_scal;
         double gp = 0.0, dp = 0.0;

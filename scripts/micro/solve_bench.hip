@@ -1,0 +1,80 @@
+// Stand-alone timing + correctness harness for cvx_amd/csrc/solve_kernels.h (development aid).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I cvx_amd/csrc scripts/micro/solve_bench.hip -o scripts/micro/solve_bench
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "solve_kernels.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 388;
+    const int C = 8, P = 108, ncf = 8, ZC = 336, camcol0 = 324, ycol = 333;
+    const int nT = (n + 1 + 31) / 32, npad = nT * 32;
+    std::vector<double> S((size_t)n * n), E((size_t)n * n + 3 * n + 4, 0.0), G((size_t)n * (n + 8));
+    srand(1);
+    for (auto &v : G) v = rand() / (double)RAND_MAX - 0.5;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0;
+            for (int k = 0; k < n + 8; ++k) s += G[(size_t)i * (n + 8) + k] * G[(size_t)j * (n + 8) + k];
+            S[(size_t)i * n + j] = S[(size_t)j * n + i] = s;
+        }
+    for (size_t i = 0; i < (size_t)n * n; ++i) E[i] = S[i];
+    for (int i = 0; i < n; ++i) { E[(size_t)n * n + i] = rand() / (double)RAND_MAX - 0.5; E[(size_t)n * n + n + i] = 0.1; E[(size_t)n * n + 2 * n + i] = S[(size_t)i * n + i]; }
+    double *dE, *ds2, *dA, *dL, *dDs, *dintr, *dpts, *dic, *dpc, *demb, *ddelta, *dR; int *dfail;
+    std::vector<double> ones(n, 1.0);
+    CK(hipMalloc(&dE, E.size() * 8)); CK(hipMemcpy(dE, E.data(), E.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&ds2, n * 8)); CK(hipMemcpy(ds2, ones.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dA, (size_t)npad * npad * 8)); CK(hipMalloc(&dL, (size_t)npad * npad * 8)); CK(hipMemset(dL, 0, (size_t)npad * npad * 8));
+    CK(hipMalloc(&dDs, n * 8)); CK(hipMalloc(&dintr, 9 * C * 8)); CK(hipMalloc(&dpts, 3 * P * 8)); CK(hipMalloc(&dic, 9 * C * 8)); CK(hipMalloc(&dpc, 3 * P * 8));
+    CK(hipMemset(dintr, 0, 9 * C * 8)); CK(hipMemset(dpts, 0, 3 * P * 8));
+    CK(hipMalloc(&demb, (size_t)C * ZC * 8)); CK(hipMalloc(&ddelta, n * 8)); CK(hipMalloc(&dR, 16 * 8)); CK(hipMalloc(&dfail, 4));
+    hipEvent_t ev[4]; for (int i = 0; i < 4; ++i) CK(hipEventCreate(&ev[i]));
+    cvxs::DampArgs da{dE, ds2, n, npad, 1e-4, 0.0, 1e-6, 1e32, dA, dDs};
+    cvxs::FinishArgs f{};
+    f.L = dL; f.ld = npad; f.n = n; f.npad = npad; f.E = dE; f.E_scal = (long long)n * n + 3 * n; f.nranks = 1; f.Ds = dDs; f.fail = dfail;
+    f.C = C; f.P = P; f.ncf = ncf; f.fix_k3 = 1; f.cam_free = 1; f.pts_free = 1; f.ZC = ZC; f.camcol0 = camcol0; f.ycol = ycol;
+    f.intr = dintr; f.points = dpts; f.intr_cand = dic; f.points_cand = dpc; f.ds_emb = demb; f.delta_s = ddelta; f.R = dR;
+    if (n != C * ncf + 3 * P) { f.C = 0; f.P = 0; f.pts_free = 0; f.cam_free = 0; f.ncf = 0; }
+#ifdef CVX_STAMPS
+    long long *dst; CK(hipMalloc(&dst, 8 * 256)); CK(hipMemset(dst, 0, 8 * 256)); f.stamps = dst;
+#endif
+    const size_t lds = 8 * ((size_t)npad + 32 * 33 + 8 * 32 + 256);
+    float t_d = 0, t_c = 0, t_f = 0;
+    const int reps = 20;
+    for (int rep = 0; rep < reps + 2; ++rep) {
+        CK(hipMemset(dfail, 0, 4));
+        CK(hipEventRecord(ev[0]));
+        hipLaunchKernelGGL(cvxs::k_damp_prepare, dim3((npad * npad + 255) / 256), dim3(256), 0, 0, da);
+        CK(hipEventRecord(ev[1]));
+        for (int k = 0; k < nT; ++k) {
+            const int ntr = nT - 1 - k, blocks = ntr > 0 ? ntr * (ntr + 1) / 2 : 1;
+            hipLaunchKernelGGL(cvxs::k_chol_step, dim3(blocks), dim3(256), 0, 0, dA, dL, npad, n, k, nT, dfail);
+        }
+        CK(hipEventRecord(ev[2]));
+        hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(256), lds, 0, f);
+        CK(hipEventRecord(ev[3]));
+        CK(hipDeviceSynchronize());
+        float a, b, c;
+        CK(hipEventElapsedTime(&a, ev[0], ev[1])); CK(hipEventElapsedTime(&b, ev[1], ev[2])); CK(hipEventElapsedTime(&c, ev[2], ev[3]));
+        if (rep >= 2) { t_d += a; t_c += b; t_f += c; }
+    }
+    printf("n=%d nT=%d  damp %.1f us  chol %.1f us (%.1f/step)  finish %.1f us\n", n, nT, 1e3 * t_d / reps, 1e3 * t_c / reps, 1e3 * t_c / reps / nT, 1e3 * t_f / reps);
+#ifdef CVX_STAMPS
+    { std::vector<long long> st(256); CK(hipMemcpy(st.data(), dst, 8 * 256, hipMemcpyDeviceToHost));
+      for (int i = 1; i < 256 && st[i]; ++i) printf("%lld ", (st[i] - st[i - 1]) * 10); printf(" ns\n"); }
+#endif
+    // check: (S + D) x = -gred
+    std::vector<double> x(n), Ds(n); int fail;
+    CK(hipMemcpy(x.data(), ddelta, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Ds.data(), dDs, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&fail, dfail, 4, hipMemcpyDeviceToHost));
+    double rmax = 0, bmax = 0;
+    for (int i = 0; i < n; ++i) {
+        double s = Ds[i] * x[i];
+        for (int j = 0; j < n; ++j) s += S[(size_t)i * n + j] * x[j];
+        rmax = fmax(rmax, fabs(s + E[(size_t)n * n + i])); bmax = fmax(bmax, fabs(E[(size_t)n * n + i]));
+    }
+    printf("fail=%d  residual max %.3e (rhs max %.3e)\n", fail, rmax, bmax);
+    return (fail || !(rmax < 1e-9 * bmax * n)) ? 1 : 0;
+}
