@@ -194,7 +194,7 @@ def main():
             # residual + Jacobian + 16x16 Gram + point blocks: SURVEY.md 8(d) 1 100 flop / observation
             "normal_eq": ("mfma", 1100.0 * N, "TFLOP/s", F64_PEAK_TFLOPS, 1e12),
             # slab reduction + assembly: read every partial tile once, write S once
-            "assemble": ("hbm", 8.0 * (geo["n_chunks"] * geo["tile_pairs"] * 48 * 48 + ns * ns), "GB/s", HBM_PEAK_GBS, 1e9),
+            "assemble": ("hbm", 8.0 * (geo["n_chunks"] * geo["tile_pairs"] * 256 + ns * ns), "GB/s", HBM_PEAK_GBS, 1e9),
             "backsubst": ("hbm", 8.0 * 6 * V * geo["ZC"], "GB/s", HBM_PEAK_GBS, 1e9),
             "cost": ("hbm", 24.0 * N, "GB/s", HBM_PEAK_GBS, 1e9),
             # damped reduced solve: Cholesky ns^3 / 3 flop (latency-bound chain of tile columns)

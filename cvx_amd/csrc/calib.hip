@@ -48,7 +48,8 @@ struct cvx_calib {
     int fix_k3 = 1, fix_intr = 0, fix_pts = 0, device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int ncf = 0, cam_free = 0, pts_free = 0, ns = 0, ZC = 0, camcol0 = 0, ycol = 0, nt = 0, ntp = 0, nbc = 0;
+    int ncf = 0, cam_free = 0, pts_free = 0, ns = 0, ZC = 0, camcol0 = 0, ycol = 0, nb = 0, nblk = 0, parts = 1, ZCp = 0, KB = 16;
+    size_t k3_lds = 0;
     int T = 64;
     size_t k2_lds = 0;
     int n_groups = 0, n_chunks = 0, n_cost_blocks = 0;
@@ -188,10 +189,11 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
     if (schur) {
         K3Args k;
         k.Z = h->d_Z; k.chk_row0 = h->d_chk_row0; k.slab = h->d_slab_tile;
-        k.ZC = h->ZC; k.n_chunks = h->n_chunks; k.nt = h->nt; k.ntp = h->ntp; k.nbc = h->nbc;
-        const int blocks = 8 * ((h->n_chunks + 7) / 8) * h->nbc;
+        k.ZC = h->ZC; k.ZCp = h->ZCp; k.KB = h->KB; k.n_chunks = h->n_chunks; k.nb = h->nb; k.nblk = h->nblk; k.parts = h->parts;
+        const int blocks = 8 * ((h->n_chunks + 7) / 8) * h->parts;
+        CVX_HIP(hipFuncSetAttribute((const void *)k_schur_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
         ph_begin(h, PH_SCHUR);
-        hipLaunchKernelGGL(k_schur_syrk, dim3(blocks), dim3(256), 0, h->stream, k);
+        hipLaunchKernelGGL(k_schur_syrk, dim3(blocks), dim3(64 * K3_WAVES), h->k3_lds, h->stream, k);
         CVX_HIP(hipGetLastError());
         ph_end(h, PH_SCHUR);
     }
@@ -208,7 +210,7 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         hipLaunchKernelGGL(k_group_sum, dim3(4, h->C), dim3(256), 0, h->stream, h->d_slab_cam, (size_t)256, 256,
                            h->d_glist, h->d_glist_off, h->d_Gcam);
         if (schur) {
-            const int n_out = h->ntp * ZTILE * ZTILE;
+            const int n_out = h->nblk * 256;
             hipLaunchKernelGGL(k_group_sum, dim3((n_out + 63) / 64, h->C), dim3(256), 0, h->stream, h->d_slab_tile,
                                (size_t)n_out, n_out, h->d_clist, h->d_clist_off, h->d_Tt);
         }
@@ -220,7 +222,7 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         AsmArgs s;
         s.Tt = schur ? h->d_Tt : nullptr; s.Tpt = h->d_Tpt; s.Gcam = h->d_Gcam;
         s.ns = h->ns; s.C = h->C; s.P = h->P; s.ncf = h->ncf; s.fix_k3 = h->fix_k3; s.pts_free = h->pts_free;
-        s.ZC = h->ZC; s.camcol0 = h->camcol0; s.ycol = h->ycol; s.nt = h->nt; s.ntp = h->ntp;
+        s.ZC = h->ZC; s.camcol0 = h->camcol0; s.ycol = h->ycol; s.nb = h->nb; s.nblk = h->nblk;
         s.E = h->d_E;
         const long long n = (long long)h->ns * h->ns + h->ns;
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, s);
@@ -443,10 +445,15 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     h->ns = C * h->ncf + (h->pts_free ? 3 * P : 0);
     h->camcol0 = h->pts_free ? 3 * P : 0;
     h->ycol = h->camcol0 + (h->cam_free ? 9 : 0);
-    h->ZC = ((h->ycol + 1 + ZTILE - 1) / ZTILE) * ZTILE;
-    h->nt = h->ZC / ZTILE;
-    h->ntp = h->nt * (h->nt + 1) / 2;
-    h->nbc = (h->ntp + 3) / 4;
+    h->ZC = ((h->ycol + 1 + 15) / 16) * 16;
+    h->nb = h->ZC / 16;
+    h->nblk = h->nb * (h->nb + 1) / 2;
+    h->parts = (h->nblk + K3_CAP - 1) / K3_CAP;
+    h->ZCp = h->ZC + ((h->ZC % 32 == 16) ? 0 : 16);        // LDS row pitch = 16 mod 32 doubles
+    h->KB = 16;
+    while (h->KB > 4 && (h->KB * h->ZC > 6144 || 2 * (size_t)h->KB * h->ZCp * sizeof(double) > 128 * 1024)) h->KB -= 4;
+    h->k3_lds = 2 * (size_t)h->KB * h->ZCp * sizeof(double);
+    if (h->KB * h->ZC > 6144 || h->k3_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
     h->T = maxn <= 64 ? 64 : maxn <= 128 ? 128 : maxn <= 256 ? 256 : 512;
     const int W = h->T / 64;
     h->k2_lds = sizeof(double) * ((size_t)P * PT_ACC + (size_t)W * 64 * AROW + (size_t)W * 256 + 256);
@@ -468,7 +475,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         }
         grp_v0.push_back(V);
         h->n_groups = (int)grp_cam.size();
-        const int target_chunks = std::max(1, 2048 / std::max(1, h->ntp));
+        const int target_chunks = std::max(1, 256 / std::max(1, h->parts));
         const int gpc = std::max(1, (h->n_groups + target_chunks - 1) / target_chunks);
         int g = 0;
         while (g < h->n_groups) {
@@ -535,10 +542,10 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_HIP(hipMemsetAsync(h->d_slab_pt, 0, std::max<size_t>(1, (size_t)h->n_groups * P * PT_ACC) * sizeof(double), s));
     CVX_TRY(dev_alloc(&h->d_slab_cam, (size_t)h->n_groups * 256));
     CVX_TRY(dev_alloc(&h->d_grp_scal, (size_t)h->n_groups * 4));
-    CVX_TRY(dev_alloc(&h->d_slab_tile, (size_t)h->n_chunks * h->ntp * ZTILE * ZTILE));
+    CVX_TRY(dev_alloc(&h->d_slab_tile, (size_t)h->n_chunks * h->nblk * 256));
     CVX_TRY(dev_alloc(&h->d_Tpt, (size_t)C * P * PT_ACC));
     CVX_HIP(hipMemsetAsync(h->d_Tpt, 0, (size_t)C * P * PT_ACC * sizeof(double), s));
-    CVX_TRY(dev_alloc(&h->d_Tt, (size_t)C * h->ntp * ZTILE * ZTILE));
+    CVX_TRY(dev_alloc(&h->d_Tt, (size_t)C * h->nblk * 256));
     CVX_TRY(dev_alloc(&h->d_Gcam, (size_t)C * 256));
     CVX_TRY(alloc_exchange(h));
     CVX_TRY(dev_alloc(&h->d_ds_emb, (size_t)C * h->ZC));
@@ -734,7 +741,7 @@ extern "C" int cvx_calib_phase_times(cvx_calib *h, double ms[16]) {
 // [4] upper-triangular tile pairs, [5] K2 threads per block, [6] Z rows
 extern "C" int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]) {
     if (!h || !out) return CVX_ERR_INVALID_ARG;
-    out[0] = h->ZC; out[1] = h->ns; out[2] = h->n_groups; out[3] = h->n_chunks; out[4] = h->ntp;
+    out[0] = h->ZC; out[1] = h->ns; out[2] = h->n_groups; out[3] = h->n_chunks; out[4] = h->nblk;
     out[5] = h->T; out[6] = 6LL * h->V; out[7] = 0;
     return CVX_OK;
 }

@@ -19,7 +19,6 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int RT_STRIDE = 40;    // per view: R[9] | dR/dw_j [3][9] | t[3] | pad
 constexpr int PT_ACC = 36;       // per point accumulators: Ucx[9][3] | Uxx[6] | gx[3]
 constexpr int AROW = 18;         // LDS stride (doubles) of one staged Jacobian row (16 + pad)
-constexpr int ZTILE = 48;        // Schur tile edge: 3 x 3 MFMA 16x16 blocks per wave
 
 // -----------------------------------------------------------------------------------------
 // K0: per-view rotation matrix and its derivative w.r.t. the global angle-axis vector
@@ -464,78 +463,103 @@ __global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
 }
 
 // -----------------------------------------------------------------------------------------
-// K3: Schur contraction  Z^T Z  on fp64 MFMA (v_mfma_f64_16x16x4_f64).
-// One wave per (48x48 upper-triangular tile, chunk of rows); partial tiles go to a slab and
-// are summed in fixed order by k_assemble.  Blocks are dealt round-robin over the 8 XCDs, so
-// the remap below keeps all tiles of one chunk on one XCD (one L2 holds that chunk's rows).
+// K3: Schur contraction  S_local = Z^T Z  on fp64 MFMA (v_mfma_f64_16x16x4_f64): a SYRK with
+// K = 6V rows and N = ZC columns.  The upper triangle is cut into 16x16 blocks (row-major over the
+// triangle); a workgroup of 12 waves owns one chunk of Z rows and one "part" of at most
+// 12 x 10 = 120 blocks, ten accumulators per wave.  The chunk's rows stream through LDS in
+// double-buffered stages of KB rows (16-byte coalesced loads of whole rows, staged in registers
+// while the previous stage is being multiplied), so every Z row is read from HBM once per part and
+// every MFMA operand comes from LDS: lane (kq, cq) reads Z[4 ks + kq][16 blk + cq], conflict-free
+// because the LDS row pitch is 16 mod 32 doubles.  Partial blocks go to a slab
+// [chunk][block][16*16] and are summed in fixed order by k_group_sum.
+// blockIdx -> (chunk, part): the parts of one chunk sit on one XCD (blockIdx % 8), which keeps the
+// second read of the chunk's rows in that XCD's L2.
 // -----------------------------------------------------------------------------------------
+constexpr int K3_WAVES = 12, K3_MAXB = 10, K3_CAP = K3_WAVES * K3_MAXB;
+
 struct K3Args {
     const double *Z;
     const int *chk_row0;   // [n_chunks + 1] first row of each chunk
-    double *slab;          // [n_chunks][ntp][48*48]
-    int ZC, n_chunks, nt, ntp, nbc;
+    double *slab;          // [n_chunks][nblk][256]
+    int ZC, ZCp, KB, n_chunks, nb, nblk, parts;
 };
 
-__global__ void __launch_bounds__(256) k_schur_syrk(K3Args a) {
+__global__ void __launch_bounds__(64 * K3_WAVES) k_schur_syrk(K3Args a) {
+    extern __shared__ double lds[];      // [2][KB][ZCp]
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int chunk = (slot / a.nbc) * 8 + xcd;
+    const int part = slot % a.parts, chunk = (slot / a.parts) * 8 + xcd;
     if (chunk >= a.n_chunks) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tp = (slot % a.nbc) * 4 + wave;
-    if (tp >= a.ntp) return;
-    int ti = 0, rem = tp;
-    while (rem >= a.nt - ti) { rem -= a.nt - ti; ++ti; }
-    const int tj = ti + rem;
-    const int r0 = a.chk_row0[chunk], r1 = a.chk_row0[chunk + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane >> 4, cq = lane & 15;
-    const double *pa = a.Z + ti * ZTILE + cq;
-    const double *pb = a.Z + tj * ZTILE + cq;
-    const bool diag = (ti == tj);
-    f64x4 acc[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-    double ca[3], cb[3];
+    const int r0 = a.chk_row0[chunk], r1 = a.chk_row0[chunk + 1];
+    const int ZC = a.ZC, ZCp = a.ZCp, KB = a.KB;
+    // this wave's blocks: q0 .. q0 + cnt of this part
+    const int pcap = (a.nblk + a.parts - 1) / a.parts;
+    const int pq0 = part * pcap, pq1 = min(a.nblk, pq0 + pcap);
+    const int per = (pq1 - pq0 + K3_WAVES - 1) / K3_WAVES;
+    const int q0 = pq0 + wave * per;
+    const int cnt = max(0, min(per, pq1 - q0));
+    int offA[K3_MAXB], offB[K3_MAXB];
     {
-        const int row = r0 + kq;
-        const bool ok = row < r1;
-        const size_t off = (size_t)(ok ? row : r0) * a.ZC;
+        int bi = 0, rem = q0;
+        while (bi < a.nb && rem >= a.nb - bi) { rem -= a.nb - bi; ++bi; }
+        int bj = bi + rem;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            ca[i] = ok ? pa[off + 16 * i] : 0.0;
-            cb[i] = diag ? ca[i] : (ok ? pb[off + 16 * i] : 0.0);
+        for (int i = 0; i < K3_MAXB; ++i) {
+            offA[i] = min(bi, a.nb - 1) * 16; offB[i] = min(bj, a.nb - 1) * 16;
+            if (++bj >= a.nb) { ++bi; bj = bi; }
         }
     }
-    for (int k = r0; k < r1; k += 4) {
-        double na[3], nb[3];
-        {
-            const int row = k + 4 + kq;
-            const bool ok = row < r1;
-            const size_t off = (size_t)(ok ? row : r0) * a.ZC;
+    f64x4 acc[K3_MAXB];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                na[i] = ok ? pa[off + 16 * i] : 0.0;
-                nb[i] = diag ? na[i] : (ok ? pb[off + 16 * i] : 0.0);
-            }
+    for (int i = 0; i < K3_MAXB; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    // staging: KB rows x ZC/2 double2 per stage, 4 per thread at most
+    const int halfc = ZC >> 1, per_stage = KB * halfc;
+    constexpr int NLD = 4;
+    const int nstages = (r1 - r0 + KB - 1) / KB;
+    double2 st[NLD];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 64 * K3_WAVES * i;
+            const int row = e / halfc, c2 = e - row * halfc;
+            const int grow = r0 + s * KB + row;
+            st[i] = double2{0.0, 0.0};
+            if (e < per_stage && grow < r1) st[i] = *(const double2 *)(a.Z + (size_t)grow * ZC + 2 * c2);
         }
+    };
+    auto stash = [&](int buf) {
+        double *dst = lds + (size_t)buf * KB * ZCp;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 64 * K3_WAVES * i;
+            const int row = e / halfc, c2 = e - row * halfc;
+            if (e < per_stage) *(double2 *)(dst + row * ZCp + 2 * c2) = st[i];
+        }
+    };
+    if (nstages > 0) { fetch(0); stash(0); }
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) fetch(s + 1);
+        const double *src = lds + (size_t)(s & 1) * KB * ZCp + kq * ZCp + cq;
+        for (int ks = 0; ks < KB; ks += 4) {
+            const double *p = src + ks * ZCp;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i], cb[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+            for (int i = 0; i < K3_MAXB; ++i)
+                if (i < cnt) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[offA[i]], p[offB[i]], acc[i], 0, 0, 0);
+        }
+        if (s + 1 < nstages) stash((s + 1) & 1);
+        __syncthreads();
     }
-    double *out = a.slab + ((size_t)chunk * a.ntp + tp) * (ZTILE * ZTILE);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < K3_MAXB; ++i)
+        if (i < cnt) {
+            double *out = a.slab + ((size_t)chunk * a.nblk + q0 + i) * 256;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) out[(16 * i + kq + 4 * q) * ZTILE + 16 * j + cq] = acc[i][j][q];
+            for (int q = 0; q < 4; ++q) out[(kq + 4 * q) * 16 + cq] = acc[i][q];
+        }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -543,7 +567,7 @@ __global__ void __launch_bounds__(256) k_schur_syrk(K3Args a) {
 // of src[slab * stride + e]; a block is 64 consecutive outputs x 4 slices of the list, so every
 // load is a coalesced 512 B row segment and the four partial sums are combined as (0+1)+(2+3).
 // Used for the per-point accumulators (slab_pt -> Tpt[C][P*36]), the per-camera Gram tiles
-// (slab_cam -> Gcam[C][256]) and the Schur tiles (slab_tile -> Tt[C][ntp*48*48]).
+// (slab_cam -> Gcam[C][256]) and the Schur tiles (slab_tile -> Tt[C][nblk*256]).
 // -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_group_sum(const double *__restrict__ src, size_t stride, int n_out,
                                                    const int *__restrict__ list, const int *__restrict__ list_off,
@@ -597,11 +621,11 @@ __global__ void __launch_bounds__(256) k_lin_scalars(const double *__restrict__ 
 //   E = [ S = U - Z^T Z (ns*ns) | gred (ns) | gs (ns) | diagU (ns) | scalars... ]
 // shared-parameter order (API): free intrinsics of camera 0, 1, ..., then points xyz.
 // Inputs are the per-camera sums made by k_group_sum: Tpt[C][P][36] (Ucx 27 | Uxx 6 | gx 3),
-// Gcam[C][256], Tt[C][ntp][48*48] (null when the Schur term is absent).
+// Gcam[C][256], Tt[C][nblk][16*16] (null when the Schur term is absent).
 // -----------------------------------------------------------------------------------------
 struct AsmArgs {
     const double *Tt, *Tpt, *Gcam;
-    int ns, C, P, ncf, fix_k3, pts_free, ZC, camcol0, ycol, nt, ntp;
+    int ns, C, P, ncf, fix_k3, pts_free, ZC, camcol0, ycol, nb, nblk;
     double *E;
 };
 
@@ -624,18 +648,19 @@ __device__ __forceinline__ SharedIdx shared_index(const AsmArgs &a, int i) {
     return s;
 }
 
-// offset of Z^T Z entry (zi, zj) inside one camera's tile block
+// offset of Z^T Z entry (zi, zj) inside one camera's block array [nblk][16*16] (upper triangle,
+// row-major over blocks)
 __device__ __forceinline__ size_t tile_offset(const AsmArgs &a, int zi, int zj) {
-    int ti = zi / ZTILE, tj = zj / ZTILE;
-    if (ti > tj) { int t = ti; ti = tj; tj = t; t = zi; zi = zj; zj = t; }
-    const int tp = ti * a.nt - ti * (ti - 1) / 2 + (tj - ti);
-    return (size_t)tp * (ZTILE * ZTILE) + (zi % ZTILE) * ZTILE + (zj % ZTILE);
+    int bi = zi >> 4, bj = zj >> 4;
+    if (bi > bj) { int t = bi; bi = bj; bj = t; t = zi; zi = zj; zj = t; }
+    const int q = bi * a.nb - bi * (bi - 1) / 2 + (bj - bi);
+    return (size_t)q * 256 + (zi & 15) * 16 + (zj & 15);
 }
 
 // sum of the cameras' tile entries: all cameras (cam < 0) or one
 __device__ __forceinline__ double tile_sum(const AsmArgs &a, int cam, int zi, int zj) {
     if (!a.Tt) return 0.0;
-    const size_t off = tile_offset(a, zi, zj), cs = (size_t)a.ntp * (ZTILE * ZTILE);
+    const size_t off = tile_offset(a, zi, zj), cs = (size_t)a.nblk * 256;
     if (cam >= 0) return a.Tt[cam * cs + off];
     double z = 0.0;
     for (int c = 0; c < a.C; ++c) z += a.Tt[c * cs + off];

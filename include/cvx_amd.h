@@ -189,7 +189,7 @@ int cvx_calib_enable_timing(cvx_calib *h, int enable);
 int cvx_calib_phase_times(cvx_calib *h, double ms[16]);
 
 /* launch geometry, for stating algorithmic work: [0] Z columns, [1] reduced-system size,
- * [2] normal-equation workgroups, [3] Schur row chunks, [4] upper-triangular tile pairs,
+ * [2] normal-equation workgroups, [3] Schur row chunks, [4] 16x16 blocks of the upper triangle of Z^T Z,
  * [5] threads per normal-equation workgroup, [6] Z rows (6 * n_views) */
 int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]);
 
