@@ -363,7 +363,7 @@ private:
                            (long long)h->N, h->d_cost_partial);
         CVX_HIP(hipGetLastError());
         ph_end(h, PH_COST);
-        hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(256), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
+        hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
                            h->d_out_view, h->V, h->d_E2);
         CVX_HIP(hipGetLastError());
         if (h->nranks > 1 && h->xfn && h->xdev) {
@@ -618,7 +618,7 @@ extern "C" int cvx_calib_cost(cvx_calib *h, double *cost) {
                        h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur], h->d_points[h->cur], h->d_rt,
                        (long long)h->N, h->d_cost_partial);
     CVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(256), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
+    hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
                        h->d_out_view, 0, h->d_E2);
     CVX_HIP(hipGetLastError());
     CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -637,7 +637,7 @@ extern "C" int cvx_calib_evaluate_device(cvx_calib *h, void **device_buffer) {
     int st = launch_pose_prepare(h, h->d_poses[h->cur]);
     if (st) return st;
     if (h->N > 0) {
-        hipLaunchKernelGGL(k_eval, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->d_view_id,
+        hipLaunchKernelGGL(k_eval, dim3((unsigned)((h->N + 511) / 512)), dim3(256), 0, h->stream, h->d_view_id,
                            h->d_cam_of_view, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur],
                            h->d_points[h->cur], h->d_rt, (long long)h->N, h->d_eval);
         CVX_HIP(hipGetLastError());

@@ -153,29 +153,57 @@ __device__ __forceinline__ void reproj_jacobian(const Intr &in, const double *__
 // K1: evaluation mode -- residuals and Jacobian blocks materialised as component planes
 // out layout (doubles): r[2][N] | Jc[18][N] | Jp[12][N] | Jx[6][N]
 // -----------------------------------------------------------------------------------------
+// Two consecutive observations per lane, so that every plane is written with 16-byte stores
+// (1 KiB per wave instruction); the odd tail observation, if any, goes through the same code with
+// the second slot masked.
 __global__ void __launch_bounds__(256) k_eval(const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
                                               const int *__restrict__ point_id, const double *__restrict__ obs_x,
                                               const double *__restrict__ obs_y, const double *__restrict__ intr,
                                               const double *__restrict__ points, const double *__restrict__ rt,
                                               long long N, double *__restrict__ out) {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long o = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
     if (o >= N) return;
-    const int v = view_id[o], pid = point_id[o];
-    const Intr in = load_intr(intr + 9 * cam_of_view[v]);
-    const double *X = points + 3 * pid;
-    double r0, r1, Jp[12], Jc[18], Jx[6];
-    reproj_jacobian(in, rt + (size_t)v * RT_STRIDE, X[0], X[1], X[2], obs_x[o], obs_y[o], r0, r1, Jp, Jc, Jx);
-    double *p = out + o;
-    p[0] = r0; p[N] = r1;
-    p += 2 * N;
+    const bool two = o + 1 < N;
+    double r[2][2], Jp[2][12], Jc[2][18], Jx[2][6];
 #pragma unroll
-    for (int i = 0; i < 18; ++i) p[(long long)i * N] = Jc[i];
-    p += 18 * N;
+    for (int u = 0; u < 2; ++u) {
+        const long long ou = (u == 0 || two) ? o + u : o;
+        const int v = view_id[ou], pid = point_id[ou];
+        const Intr in = load_intr(intr + 9 * cam_of_view[v]);
+        const double *X = points + 3 * pid;
+        reproj_jacobian(in, rt + (size_t)v * RT_STRIDE, X[0], X[1], X[2], obs_x[ou], obs_y[ou], r[u][0], r[u][1], Jp[u], Jc[u], Jx[u]);
+    }
+    // planes start at multiples of N doubles: 16-byte aligned pairs need N even
+    if (two && !(N & 1)) {
+        double2 *p = (double2 *)(out + o);
+        const long long h = N >> 1;
+        p[0] = double2{r[0][0], r[1][0]}; p[h] = double2{r[0][1], r[1][1]};
+        p += 2 * h;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) p[(long long)i * N] = Jp[i];
-    p += 12 * N;
+        for (int i = 0; i < 18; ++i) p[(long long)i * h] = double2{Jc[0][i], Jc[1][i]};
+        p += 18 * h;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) p[(long long)i * N] = Jx[i];
+        for (int i = 0; i < 12; ++i) p[(long long)i * h] = double2{Jp[0][i], Jp[1][i]};
+        p += 12 * h;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p[(long long)i * h] = double2{Jx[0][i], Jx[1][i]};
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            double *p = out + o + u;
+            p[0] = r[u][0]; p[N] = r[u][1];
+            p += 2 * N;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) p[(long long)i * N] = Jc[u][i];
+            p += 18 * N;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) p[(long long)i * N] = Jp[u][i];
+            p += 12 * N;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p[(long long)i * N] = Jx[u][i];
+        }
+    }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -718,7 +746,7 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
 // K6: back-substitution, one wave per view:
 //   t = Z_v * ds_emb[cam]  (ds_emb has 1 in the y column)   ->  dp = -Linv^T t
 //   candidate pose = pose + dp;  per-view sums for the step evaluation
-// out_view[v] = { dp^T (D dp - g), |dp|^2, |pose|^2 }
+// out_view[k][v] (three planes) = dp^T (D dp - g), |dp|^2, |pose|^2
 // -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z, const double *__restrict__ Linv,
                                                    const double *__restrict__ Dv, const double *__restrict__ gv,
@@ -758,35 +786,51 @@ __global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z,
             s2 += dp * dp;
             x2 += p * p;
         }
-        out_view[3 * v] = m;
-        out_view[3 * v + 1] = s2;
-        out_view[3 * v + 2] = x2;
+        out_view[v] = m;
+        out_view[V + v] = s2;
+        out_view[2 * (size_t)V + v] = x2;
     }
 }
 
 // -----------------------------------------------------------------------------------------
-// final scalar reduction (single block, fixed order):
-//   E2 = { sum cost partials, sum out_view[.][0], sum out_view[.][1], sum out_view[.][2] }
+// final scalar reduction (single block of 1024, fixed order):
+//   E2 = { sum cost partials, sum out_view[0][.], sum out_view[1][.], sum out_view[2][.] }
+// each thread sums a strided slice, eight independent loads in flight at a time
 // -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_final_scalars(const double *__restrict__ cost_partial, int n_partial,
-                                                       const double *__restrict__ out_view, int V,
-                                                       double *__restrict__ E2) {
-    __shared__ double sh[4][256];
-    double s[4] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < n_partial; i += 256) s[0] += cost_partial[i];
-    for (int i = threadIdx.x; i < V; i += 256) {
-        s[1] += out_view[3 * i];
-        s[2] += out_view[3 * i + 1];
-        s[3] += out_view[3 * i + 2];
+__device__ __forceinline__ double strided_sum_1024(const double *__restrict__ p, int n) {
+    double s = 0.0;
+    int i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + u * 1024];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = s[k];
+    for (; i < n; i += 1024) s += p[i];
+    return s;
+}
+
+__global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict__ cost_partial, int n_partial,
+                                                        const double *__restrict__ out_view, int V,
+                                                        double *__restrict__ E2) {
+    __shared__ double sh[4][16];
+    double s[4];
+    s[0] = strided_sum_1024(cost_partial, n_partial);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k + 1] = strided_sum_1024(out_view + (size_t)k * V, V);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
+        if (lane == 0) sh[k][wave] = s[k];
+    }
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off)
-            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
-        __syncthreads();
+    if (threadIdx.x < 4) {
+        const double *q = sh[threadIdx.x];
+        E2[threadIdx.x] = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+                          (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
     }
-    if (threadIdx.x < 4) E2[threadIdx.x] = sh[threadIdx.x][0];
 }
 
 }  // namespace cvxk

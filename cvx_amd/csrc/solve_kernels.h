@@ -55,6 +55,13 @@ __global__ void __launch_bounds__(256) k_damp_prepare(DampArgs a) {
     a.A[t] = v;
 }
 
+#ifdef CVX_STAMPS
+__device__ long long g_cstamps[64];
+#define CSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && k == 3) g_cstamps[i] = wall_clock64(); } while (0)
+#else
+#define CSTAMP(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, srclane);
@@ -77,6 +84,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
     __shared__ double D[2][TB][TB + 1];
     __shared__ double P[2][TB][TB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    CSTAMP(0);
     const int ntr = nT - 1 - k;
     int ti = -1, tj = -1;
     if (ntr > 0) {
@@ -108,6 +116,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
         }
     }
     __syncthreads();
+    CSTAMP(1);
     if (wave < 2) {
         const int r = lane & 31;
         const bool panel = lane >= 32;
@@ -142,6 +151,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
         if (wave == 0 && __any(bad) && lane == 0) *fail = 1;
     }
     __syncthreads();
+    CSTAMP(2);
     if (blockIdx.x == 0)
         for (int e = tid; e < TB * TB; e += 256) {
             const int r = e >> 5, c = e & 31;
@@ -161,6 +171,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         A[(size_t)(ti * TB + bi * 16 + kq + 4 * q) * ld + tj * TB + bj * 16 + cq] = a_old[q] - acc[q];
+    CSTAMP(3);
 }
 
 // -----------------------------------------------------------------------------------------

@@ -7,7 +7,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int NACC>
-__global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double seed) {
+__global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double seed, long long *clk = nullptr) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     f64x4 acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = f64x4{0, 0, 0, 0};
     double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
@@ -18,6 +19,7 @@ __global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double see
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
 __global__ void __launch_bounds__(256) k_fma(double *out, int iters, double seed) {
@@ -57,7 +59,7 @@ float time_ms(F f, int reps) {
 int main() {
     double *out; CK(hipMalloc(&out, 2048 * 256 * sizeof(double)));
     const int iters = 4000;
-    for (int wps = 1; wps <= 2; ++wps) {   // waves per SIMD
+    for (int wps = 1; wps <= 4; ++wps) {   // waves per SIMD
         int blocks = 256 * wps;            // 4 waves per block -> one per SIMD per block
         float ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<4>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, 5);
         double flops = (double)blocks * 4 * iters * 4 * 2048.0;
@@ -65,6 +67,17 @@ int main() {
         ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<9>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, 5);
         flops = (double)blocks * 4 * iters * 9 * 2048.0;
         printf("mfma_f64_16x16x4 x9acc  %d wave/SIMD: %.3f ms  %.2f TFLOP/s\n", wps, ms, flops / ms / 1e9);
+    }
+    {   // in-kernel clock and cycles per MFMA (one wave's view), long enough for DVFS to settle
+        long long *clk; CK(hipMalloc(&clk, 16)); long long h[2];
+        for (int wps = 1; wps <= 4; wps *= 2) {
+            int blocks = 256 * wps;
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k_mfma<8>), dim3(blocks), dim3(256), 0, 0, out, iters * 8, 1.0, clk);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+            double ghz = (double)h[0] / ((double)h[1] * 10.0);
+            printf("mfma x8acc %d wave/SIMD: shader clock %.3f GHz, %.1f cycles per MFMA per SIMD, %.2f TFLOP/s\n", wps, ghz,
+                   (double)h[0] / (iters * 8.0 * 8 * wps), 1024.0 * wps * iters * 8.0 * 8 * 2048.0 / ((double)h[1] * 10e-9) / 1e12);
+        }
     }
     for (int wps = 1; wps <= 4; wps *= 2) {
         int blocks = 256 * wps;

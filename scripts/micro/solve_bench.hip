@@ -66,6 +66,10 @@ int main(int argc, char **argv) {
     { std::vector<long long> st(256); CK(hipMemcpy(st.data(), dst, 8 * 256, hipMemcpyDeviceToHost));
       for (int i = 1; i < 256 && st[i]; ++i) printf("%lld ", (st[i] - st[i - 1]) * 10); printf(" ns\n"); }
 #endif
+#ifdef CVX_STAMPS
+    { long long cs[64]; CK(hipMemcpyFromSymbol(cs, HIP_SYMBOL(cvxs::g_cstamps), sizeof cs));
+      printf("chol step 3: load %lld  factor %lld  tail %lld ns\n", (cs[1]-cs[0])*10, (cs[2]-cs[1])*10, (cs[3]-cs[2])*10); }
+#endif
     // check: (S + D) x = -gred
     std::vector<double> x(n), Ds(n); int fail;
     CK(hipMemcpy(x.data(), ddelta, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Ds.data(), dDs, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&fail, dfail, 4, hipMemcpyDeviceToHost));
