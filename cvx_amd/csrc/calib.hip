@@ -62,7 +62,9 @@ struct cvx_calib {
     double *d_intr[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr}, *d_poses[2] = {nullptr, nullptr};
     int cur = 0;
     // device: work
-    double *d_rt = nullptr, *d_Z = nullptr, *d_Linv = nullptr, *d_Dv = nullptr, *d_gv = nullptr, *d_s2pose = nullptr;
+    double *d_rt[2] = {nullptr, nullptr};   // per-view R, dR/dw, t of the current / candidate poses
+    bool rt_valid[2] = {false, false};
+    double *d_Z = nullptr, *d_Linv = nullptr, *d_Dv = nullptr, *d_gv = nullptr, *d_s2pose = nullptr;
     double *d_slab_pt = nullptr, *d_slab_cam = nullptr, *d_grp_scal = nullptr, *d_slab_tile = nullptr;
     double *d_Tpt = nullptr, *d_Tt = nullptr, *d_Gcam = nullptr;
     double *d_E = nullptr, *h_E = nullptr;
@@ -95,7 +97,7 @@ cvx_calib::~cvx_calib() {
     (void)hipSetDevice(device);
     void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
-                    d_poses[1], d_rt, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
+                    d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial,
                     d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail};
     for (void *p : ptrs)
@@ -153,7 +155,7 @@ K2Args make_k2(cvx_calib *h, const cvx_damping &d) {
     K2Args a;
     a.view_off = h->d_view_off; a.cam_of_view = h->d_cam_of_view; a.point_id = h->d_point_id;
     a.obs_x = h->d_obs_x; a.obs_y = h->d_obs_y;
-    a.intr = h->d_intr[h->cur]; a.points = h->d_points[h->cur]; a.rt = h->d_rt; a.s2pose = h->d_s2pose;
+    a.intr = h->d_intr[h->cur]; a.points = h->d_points[h->cur]; a.rt = h->d_rt[h->cur]; a.s2pose = h->d_s2pose;
     a.grp_v0 = h->d_grp_v0;
     a.P = h->P; a.ZC = h->ZC; a.camcol0 = h->camcol0; a.ycol = h->ycol; a.cam_free = h->cam_free; a.pts_free = h->pts_free;
     a.inv_radius = d.inv_radius; a.mu = d.mu; a.min_diag = d.min_diag; a.max_diag = d.max_diag;
@@ -162,9 +164,11 @@ K2Args make_k2(cvx_calib *h, const cvx_damping &d) {
     return a;
 }
 
-int launch_pose_prepare(cvx_calib *h, const double *poses) {
-    if (h->V == 0) return CVX_OK;
-    hipLaunchKernelGGL(k_pose_prepare, dim3((h->V + 127) / 128), dim3(128), 0, h->stream, poses, h->d_rt, h->V);
+// rotation tables of parameter buffer `which` (skipped while they are still valid for it)
+int launch_pose_prepare(cvx_calib *h, int which) {
+    if (h->V == 0 || h->rt_valid[which]) return CVX_OK;
+    h->rt_valid[which] = true;
+    hipLaunchKernelGGL(k_pose_prepare, dim3((h->V + 127) / 128), dim3(128), 0, h->stream, h->d_poses[which], h->d_rt[which], h->V);
     CVX_HIP(hipGetLastError());
     return CVX_OK;
 }
@@ -173,7 +177,7 @@ int launch_pose_prepare(cvx_calib *h, const double *poses) {
 // contraction, fixed-order slab sums, assembly of E, and the exchange step.  Nothing is copied to
 // the host (a host-buffer exchange hook is the exception: E makes the round trip the hook asks for).
 int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_scale) {
-    int st = launch_pose_prepare(h, h->d_poses[h->cur]);
+    int st = launch_pose_prepare(h, h->cur);
     if (st) return st;
     K2Args a = make_k2(h, d);
     ph_begin(h, PH_NORMAL);
@@ -355,11 +359,12 @@ private:
             CVX_HIP(hipGetLastError());
         }
         ph_end(h, PH_BACKSUBST);
-        st = launch_pose_prepare(h, h->d_poses[nxt]);
+        h->rt_valid[nxt] = false;
+        st = launch_pose_prepare(h, nxt);
         if (st) return st;
         ph_begin(h, PH_COST);
         hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
-                           h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[nxt], h->d_points[nxt], h->d_rt,
+                           h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[nxt], h->d_points[nxt], h->d_rt[nxt],
                            (long long)h->N, h->d_cost_partial);
         CVX_HIP(hipGetLastError());
         ph_end(h, PH_COST);
@@ -529,7 +534,8 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         CVX_HIP(hipMemsetAsync(h->d_points[k], 0, 3 * (size_t)P * sizeof(double), s));
         if (V) CVX_HIP(hipMemsetAsync(h->d_poses[k], 0, 6 * (size_t)V * sizeof(double), s));
     }
-    CVX_TRY(dev_alloc(&h->d_rt, (size_t)V * RT_STRIDE));
+    CVX_TRY(dev_alloc(&h->d_rt[0], (size_t)V * RT_STRIDE));
+    CVX_TRY(dev_alloc(&h->d_rt[1], (size_t)V * RT_STRIDE));
     const size_t zn = ((size_t)6 * V + 8) * h->ZC;
     CVX_TRY(dev_alloc(&h->d_Z, zn));
     CVX_HIP(hipMemsetAsync(h->d_Z, 0, zn * sizeof(double), s));
@@ -588,6 +594,7 @@ extern "C" int cvx_calib_set_params(cvx_calib *h, const double *intr, const doub
     if (!h || !intr || !points || (h->V > 0 && !poses)) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
     const int c = h->cur;
+    h->rt_valid[c] = false;
     CVX_HIP(hipMemcpyAsync(h->d_intr[c], intr, sizeof(double) * 9 * h->C, hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_points[c], points, sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
     if (h->V) CVX_HIP(hipMemcpyAsync(h->d_poses[c], poses, sizeof(double) * 6 * (size_t)h->V, hipMemcpyHostToDevice, h->stream));
@@ -612,10 +619,10 @@ extern "C" int cvx_calib_num_shared(const cvx_calib *h) { return h ? h->ns : -1;
 extern "C" int cvx_calib_cost(cvx_calib *h, double *cost) {
     if (!h || !cost) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
-    int st = launch_pose_prepare(h, h->d_poses[h->cur]);
+    int st = launch_pose_prepare(h, h->cur);
     if (st) return st;
     hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
-                       h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur], h->d_points[h->cur], h->d_rt,
+                       h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur], h->d_points[h->cur], h->d_rt[h->cur],
                        (long long)h->N, h->d_cost_partial);
     CVX_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
@@ -634,12 +641,12 @@ extern "C" int cvx_calib_evaluate_device(cvx_calib *h, void **device_buffer) {
         int st = dev_alloc(&h->d_eval, 38 * (size_t)h->N);
         if (st) return st;
     }
-    int st = launch_pose_prepare(h, h->d_poses[h->cur]);
+    int st = launch_pose_prepare(h, h->cur);
     if (st) return st;
     if (h->N > 0) {
-        hipLaunchKernelGGL(k_eval, dim3((unsigned)((h->N + 511) / 512)), dim3(256), 0, h->stream, h->d_view_id,
+        hipLaunchKernelGGL(k_eval, dim3((unsigned)((h->N + 127) / 128)), dim3(64), 0, h->stream, h->d_view_id,
                            h->d_cam_of_view, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur],
-                           h->d_points[h->cur], h->d_rt, (long long)h->N, h->d_eval);
+                           h->d_points[h->cur], h->d_rt[h->cur], (long long)h->N, h->d_eval);
         CVX_HIP(hipGetLastError());
     }
     if (device_buffer) *device_buffer = h->d_eval;

@@ -156,7 +156,7 @@ __device__ __forceinline__ void reproj_jacobian(const Intr &in, const double *__
 // Two consecutive observations per lane, so that every plane is written with 16-byte stores
 // (1 KiB per wave instruction); the odd tail observation, if any, goes through the same code with
 // the second slot masked.
-__global__ void __launch_bounds__(256) k_eval(const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
+__global__ void __launch_bounds__(64) k_eval(const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
                                               const int *__restrict__ point_id, const double *__restrict__ obs_x,
                                               const double *__restrict__ obs_y, const double *__restrict__ intr,
                                               const double *__restrict__ points, const double *__restrict__ rt,

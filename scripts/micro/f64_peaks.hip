@@ -44,6 +44,38 @@ __global__ void __launch_bounds__(256) k_write(double2 *__restrict__ out, size_t
     for (; i < n; i += stride) out[i] = double2{v, v};
 }
 
+__global__ void __launch_bounds__(256) k_write_nt(double2 *__restrict__ out, size_t n, double v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { __builtin_nontemporal_store(v, &out[i].x); __builtin_nontemporal_store(v, &out[i].y); }
+}
+__global__ void __launch_bounds__(256) k_write_once(double2 *__restrict__ out, size_t n, double v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = double2{v, v};
+}
+typedef double d2v __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_write_once_nt(d2v *__restrict__ out, size_t n, double v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(d2v{v, v}, &out[i]);
+}
+
+// the store pattern of k_eval: 38 planes of N doubles, each thread writes 16 B into every plane
+__global__ void __launch_bounds__(64) k_planes(double *__restrict__ out, long long N, double v) {
+    const long long o = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (o >= N) return;
+    double2 *p = (double2 *)(out + o);
+    const long long h = N >> 1;
+#pragma unroll
+    for (int i = 0; i < 38; ++i) p[i * h] = double2{v + i, v - i};
+}
+// the same bytes as tiles: [tile of 128 observations][38][128]
+__global__ void __launch_bounds__(64) k_tiles(double *__restrict__ out, long long N, double v) {
+    const long long o = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (o >= N) return;
+    double2 *p = (double2 *)(out + (size_t)blockIdx.x * 38 * 128) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 38; ++i) p[i * 64] = double2{v + i, v - i};
+}
+
 template <class F>
 float time_ms(F f, int reps) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -89,6 +121,17 @@ int main() {
     double2 *a, *b; CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&b, n * 16));
     CK(hipMemset(a, 0, n * 16));
     float ms = time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, a, b, n); }, 10);
+    { float m2 = time_ms([&] { hipLaunchKernelGGL(k_write_nt, dim3(2048), dim3(256), 0, 0, b, n, 1.0); }, 10);
+      printf("write nt (2x8B) 1 GiB: %.3f ms  %.2f TB/s\n", m2, n * 16 / m2 / 1e9);
+      m2 = time_ms([&] { hipLaunchKernelGGL(k_write_once, dim3((unsigned)(n / 256)), dim3(256), 0, 0, b, n, 1.0); }, 10);
+      printf("write one-per-thread 1 GiB: %.3f ms  %.2f TB/s\n", m2, n * 16 / m2 / 1e9);
+      m2 = time_ms([&] { hipLaunchKernelGGL(k_write_once_nt, dim3((unsigned)(n / 256)), dim3(256), 0, 0, (d2v *)b, n, 1.0); }, 10);
+      printf("write one-per-thread nt 16B 1 GiB: %.3f ms  %.2f TB/s\n", m2, n * 16 / m2 / 1e9); }
+    { const long long N = 1080000; double *ev; CK(hipMalloc(&ev, 38 * N * 8));
+      float m3 = time_ms([&] { hipLaunchKernelGGL(k_planes, dim3((unsigned)((N + 127) / 128)), dim3(64), 0, 0, ev, N, 1.0); }, 20);
+      printf("38 planes x 1.08M (k_eval store pattern): %.3f ms  %.2f TB/s\n", m3, 38.0 * N * 8 / m3 / 1e9);
+      m3 = time_ms([&] { hipLaunchKernelGGL(k_tiles, dim3((unsigned)((N + 127) / 128)), dim3(64), 0, 0, ev, N, 1.0); }, 20);
+      printf("38 x 128 tiles x 1.08M: %.3f ms  %.2f TB/s\n", m3, 38.0 * N * 8 / m3 / 1e9); }
     printf("copy 1 GiB -> 1 GiB: %.3f ms  %.2f TB/s (read+write)\n", ms, 2.0 * n * 16 / ms / 1e9);
     ms = time_ms([&] { hipLaunchKernelGGL(k_write, dim3(2048), dim3(256), 0, 0, b, n, 1.0); }, 10);
     printf("write 1 GiB: %.3f ms  %.2f TB/s\n", ms, 1.0 * n * 16 / ms / 1e9);
