@@ -51,6 +51,7 @@ struct cvx_calib {
     int ncf = 0, cam_free = 0, pts_free = 0, ns = 0, ZC = 0, camcol0 = 0, ycol = 0, nb = 0, nblk = 0, parts = 1, ZCp = 0, KB = 16;
     size_t k3_lds = 0;
     int T = 64;
+    bool aligned = false;   // every group's views list the same points in the same order
     size_t k2_lds = 0;
     int n_groups = 0, n_chunks = 0, n_cost_blocks = 0;
     std::vector<int> h_cam_of_view, h_view_off;
@@ -132,21 +133,26 @@ inline void ph_collect(cvx_calib *h) {
 template <int MODE>
 int launch_normal_eq(cvx_calib *h, const K2Args &a) {
     dim3 grid(h->n_groups);
-    switch (h->T) {
-#define CVX_CASE(TT)                                                                                          \
-    case TT:                                                                                                  \
-        CVX_HIP(hipFuncSetAttribute((const void *)k_normal_eq<TT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)h->k2_lds));                                                         \
-        hipLaunchKernelGGL((k_normal_eq<TT, MODE>), grid, dim3(TT), h->k2_lds, h->stream, a);                  \
+#define CVX_LAUNCH(TT, AL)                                                                                    \
+    do {                                                                                                      \
+        CVX_HIP(hipFuncSetAttribute((const void *)k_normal_eq<TT, MODE, AL>,                                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds));             \
+        hipLaunchKernelGGL((k_normal_eq<TT, MODE, AL>), grid, dim3(TT), h->k2_lds, h->stream, a);             \
+    } while (0)
+#define CVX_CASE(TT)                                                      \
+    case TT:                                                              \
+        if (h->aligned) CVX_LAUNCH(TT, true); else CVX_LAUNCH(TT, false); \
         break;
+    switch (h->T) {
         CVX_CASE(64)
         CVX_CASE(128)
         CVX_CASE(256)
         CVX_CASE(512)
-#undef CVX_CASE
         default:
             return CVX_ERR_UNSUPPORTED;
     }
+#undef CVX_CASE
+#undef CVX_LAUNCH
     CVX_HIP(hipGetLastError());
     return CVX_OK;
 }
@@ -159,7 +165,7 @@ K2Args make_k2(cvx_calib *h, const cvx_damping &d) {
     a.grp_v0 = h->d_grp_v0;
     a.P = h->P; a.ZC = h->ZC; a.camcol0 = h->camcol0; a.ycol = h->ycol; a.cam_free = h->cam_free; a.pts_free = h->pts_free;
     a.inv_radius = d.inv_radius; a.mu = d.mu; a.min_diag = d.min_diag; a.max_diag = d.max_diag;
-    a.Z = h->d_Z; a.Linv = h->d_Linv; a.Dv = h->d_Dv; a.gv = h->d_gv; a.s2pose_out = nullptr;
+    a.Z = h->d_Z; a.Lfac = h->d_Linv; a.Dv = h->d_Dv; a.gv = h->d_gv; a.s2pose_out = nullptr;
     a.slab_pt = h->d_slab_pt; a.slab_cam = h->d_slab_cam; a.grp_scal = h->d_grp_scal;
     return a;
 }
@@ -461,8 +467,6 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     if (h->KB * h->ZC > 6144 || h->k3_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
     h->T = maxn <= 64 ? 64 : maxn <= 128 ? 128 : maxn <= 256 ? 256 : 512;
     const int W = h->T / 64;
-    h->k2_lds = sizeof(double) * ((size_t)P * PT_ACC + (size_t)W * 64 * AROW + (size_t)W * 256 + 256);
-    if (h->k2_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
     h->h_cam_of_view.assign(d->cam_of_view, d->cam_of_view + V);
     h->h_view_off.assign(d->view_off, d->view_off + V + 1);
 
@@ -480,6 +484,18 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         }
         grp_v0.push_back(V);
         h->n_groups = (int)grp_cam.size();
+        // aligned groups: thread tid meets the same point in every view of its group
+        h->aligned = true;
+        for (size_t g = 0; g + 1 < grp_v0.size() && h->aligned; ++g) {
+            const int a0 = grp_v0[g], n0 = d->view_off[a0 + 1] - d->view_off[a0];
+            for (int vv = a0 + 1; vv < grp_v0[g + 1] && h->aligned; ++vv) {
+                if (d->view_off[vv + 1] - d->view_off[vv] != n0 ||
+                    std::memcmp(d->point_id + d->view_off[vv], d->point_id + d->view_off[a0], sizeof(int) * n0) != 0)
+                    h->aligned = false;
+            }
+        }
+        h->k2_lds = sizeof(double) * ((h->aligned ? 0 : (size_t)P * PT_ACC) + (size_t)W * 64 * AROW + (size_t)W * 256 + 256);
+        if (h->k2_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
         const int target_chunks = std::max(1, 256 / std::max(1, h->parts));
         const int gpc = std::max(1, (h->n_groups + target_chunks - 1) / target_chunks);
         int g = 0;

@@ -241,43 +241,41 @@ __global__ void __launch_bounds__(256) k_cost(const int *__restrict__ view_id, c
 }
 
 // -----------------------------------------------------------------------------------------
-// 6x6 SPD block: Cholesky factor and its inverse, packed lower triangle idx(i,j)=i(i+1)/2+j
+// 6x6 SPD block, packed lower triangle idx(i,j)=i(i+1)/2+j: Cholesky factor in place.  On return
+// the off-diagonal slots hold L and the diagonal slots 1/L_ii (all the substitutions need).
 // -----------------------------------------------------------------------------------------
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
-__device__ __forceinline__ bool chol6_inverse(const double (&A)[21], double (&M)[21]) {
-    double L[21], invd[6];
+__device__ __forceinline__ bool chol6_factor(double (&A)[21]) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double s = A[TRI(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[TRI(j, k)] * L[TRI(j, k)];
+        for (int k = 0; k < j; ++k) s -= A[TRI(j, k)] * A[TRI(j, k)];
         ok = ok && (s > 0.0) && (s < 1.7e308);
         const double ri = ok ? rsqrt(s) : 0.0;
-        invd[j] = ri;
-        L[TRI(j, j)] = s * ri;
+        A[TRI(j, j)] = ri;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = A[TRI(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= L[TRI(i, k)] * L[TRI(j, k)];
-            L[TRI(i, j)] = t * ri;
-        }
-    }
-    // M = L^-1 (lower)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        M[TRI(j, j)] = invd[j];
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = j; k < i; ++k) t += L[TRI(i, k)] * M[TRI(k, j)];
-            M[TRI(i, j)] = -t * invd[i];
+            for (int k = 0; k < j; ++k) t -= A[TRI(i, k)] * A[TRI(j, k)];
+            A[TRI(i, j)] = t * ri;
         }
     }
     return ok;
+}
+
+// z = L^-1 w with the packed factor of chol6_factor
+__device__ __forceinline__ void chol6_forward(const double (&Lf)[21], double (&w)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double t = w[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= Lf[TRI(i, k)] * w[k];
+        w[i] = t * Lf[TRI(i, i)];
+    }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -286,8 +284,8 @@ __device__ __forceinline__ bool chol6_inverse(const double (&A)[21], double (&M)
 //
 // Per view:   G = A^T A for A = [Jp | Jc | r] (rows: 2 per observation) on fp64 MFMA,
 //             giving V_v (6x6), W_vc (6x9), g_v, and this view's share of U_cc, g_c, cost;
-//             D_v from diag(V_v); Linv = chol(V_v + D_v)^-1;
-//             Z_v = Linv [W_vx | W_vc | g_v] written to HBM (row-major, ZC columns);
+//             D_v from diag(V_v); L_v = chol(V_v + D_v) (kept per view for the back-substitution);
+//             Z_v = L_v^-1 [W_vx | W_vc | g_v] written to HBM (row-major, ZC columns);
 // per point:  U_cx, U_xx, g_x accumulated in LDS across the group's views.
 // MODE 0: as above.  MODE 1 (initial linearisation): no damping/factor/Z; writes the Jacobi
 //         scales s_j^2 = 1/(1+sqrt(d_j))^2 of the pose parameters when s2pose_out != null.
@@ -298,19 +296,26 @@ struct K2Args {
     const int *grp_v0;
     int P, ZC, camcol0, ycol, cam_free, pts_free;
     double inv_radius, mu, min_diag, max_diag;
-    double *Z, *Linv, *Dv, *gv, *s2pose_out, *slab_pt, *slab_cam, *grp_scal;
+    double *Z, *Lfac, *Dv, *gv, *s2pose_out, *slab_pt, *slab_cam, *grp_scal;
 };
 
-template <int T, int MODE>
-__global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
+template <int T, int MODE, bool ALIGNED>
+__global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
     extern __shared__ double lds[];
     constexpr int W = T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *accpt = lds;                                // [P * PT_ACC]
-    double *arows = accpt + a.P * PT_ACC;               // [W][64 * AROW]
-    double *tiles = arows + W * 64 * AROW;              // [W][256]
-    double *gsum = tiles + W * 256;                     // [256]
-    for (int e = tid; e < a.P * PT_ACC; e += T) accpt[e] = 0.0;
+    // ALIGNED: every view of the group lists the same points in the same order, so thread tid meets the
+    // same point in every view and its U_cx | U_xx | g_x accumulators stay in registers; otherwise they
+    // live in LDS, indexed by point id
+    double *accpt = lds;                                            // [P * PT_ACC] (not ALIGNED)
+    double *arows = accpt + (ALIGNED ? 0 : a.P * PT_ACC);           // [W][64 * AROW]
+    double *tiles = arows + W * 64 * AROW;                          // [W][256]
+    double *gsum = tiles + W * 256;                                 // [256]
+    if (!ALIGNED)
+        for (int e = tid; e < a.P * PT_ACC; e += T) accpt[e] = 0.0;
+    double pacc[PT_ACC];
+#pragma unroll
+    for (int i = 0; i < PT_ACC; ++i) pacc[i] = 0.0;
 
     const int g = blockIdx.x;
     const int v0 = a.grp_v0[g], v1 = a.grp_v0[g + 1];
@@ -319,6 +324,12 @@ __global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
     f64x4 acc_tot = {0.0, 0.0, 0.0, 0.0};
     double gmax = 0.0, dmax = 0.0, nbad = 0.0;
     double *myrows = arows + wave * 64 * AROW;
+    int pid = 0;
+    double X0 = 0.0, X1 = 0.0, X2 = 0.0;
+    if (ALIGNED && v0 < v1 && tid < a.view_off[v0 + 1] - a.view_off[v0]) {
+        pid = a.point_id[a.view_off[v0] + tid];
+        X0 = a.points[3 * pid]; X1 = a.points[3 * pid + 1]; X2 = a.points[3 * pid + 2];
+    }
     __syncthreads();
 
     for (int v = v0; v < v1; ++v) {
@@ -327,11 +338,12 @@ __global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
         const double *rt = a.rt + (size_t)v * RT_STRIDE;
         const bool active = tid < n;
         double r[2] = {0.0, 0.0}, Jp[12], Jc[18], Jx[6];
-        int pid = 0;
         if (active) {
-            pid = a.point_id[base + tid];
-            const double *X = a.points + 3 * pid;
-            reproj_jacobian(in, rt, X[0], X[1], X[2], a.obs_x[base + tid], a.obs_y[base + tid], r[0], r[1], Jp, Jc, Jx);
+            if (!ALIGNED) {
+                pid = a.point_id[base + tid];
+                X0 = a.points[3 * pid]; X1 = a.points[3 * pid + 1]; X2 = a.points[3 * pid + 2];
+            }
+            reproj_jacobian(in, rt, X0, X1, X2, a.obs_x[base + tid], a.obs_y[base + tid], r[0], r[1], Jp, Jc, Jx);
         } else {
 #pragma unroll
             for (int i = 0; i < 12; ++i) Jp[i] = 0.0;
@@ -339,6 +351,33 @@ __global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
             for (int i = 0; i < 18; ++i) Jc[i] = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) Jx[i] = 0.0;
+        }
+        // ---- per-point accumulators (unique point ids inside a view: plain read-modify-write) ----
+        if (active && a.pts_free) {
+            double inc[PT_ACC];
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) inc[c * 3 + b] = Jc[c] * Jx[b] + Jc[9 + c] * Jx[3 + b];
+            inc[27] = Jx[0] * Jx[0] + Jx[3] * Jx[3];
+            inc[28] = Jx[0] * Jx[1] + Jx[3] * Jx[4];
+            inc[29] = Jx[0] * Jx[2] + Jx[3] * Jx[5];
+            inc[30] = Jx[1] * Jx[1] + Jx[4] * Jx[4];
+            inc[31] = Jx[1] * Jx[2] + Jx[4] * Jx[5];
+            inc[32] = Jx[2] * Jx[2] + Jx[5] * Jx[5];
+            inc[33] = Jx[0] * r[0] + Jx[3] * r[1];
+            inc[34] = Jx[1] * r[0] + Jx[4] * r[1];
+            inc[35] = Jx[2] * r[0] + Jx[5] * r[1];
+            if (ALIGNED) {
+#pragma unroll
+                for (int i = 0; i < PT_ACC; ++i)
+                    if (i >= 27 || a.cam_free) pacc[i] += inc[i];
+            } else {
+                double *pa = accpt + pid * PT_ACC;
+#pragma unroll
+                for (int i = 0; i < PT_ACC; ++i)
+                    if (i >= 27 || a.cam_free) pa[i] += inc[i];
+            }
         }
         // ---- Gram of the staged rows on the matrix cores ----
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -402,24 +441,19 @@ __global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
             }
         }
         if (MODE == 0) {
-            double M[21];
-            const bool ok = chol6_inverse(A, M);
+            const bool ok = chol6_factor(A);
             if (!ok) nbad = 1.0;
             double *Zv = a.Z + (size_t)6 * v * a.ZC;
-            // point columns: Z[a][3 pid + b] = sum_{k<=a} M[a][k] (Jp^T Jx)[k][b]
+            // point columns: Z[.][3 pid + b] = L^-1 (Jp^T Jx)[.][b]
             if (active && a.pts_free) {
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     double w[6];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) w[k] = Jp[k] * Jx[b] + Jp[6 + k] * Jx[3 + b];
+                    chol6_forward(A, w);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        double z = 0.0;
-#pragma unroll
-                        for (int k = 0; k <= i; ++k) z += M[TRI(i, k)] * w[k];
-                        Zv[(size_t)i * a.ZC + 3 * pid + b] = z;
-                    }
+                    for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + 3 * pid + b] = w[i];
                 }
             }
             // camera columns (lanes 0..8), reduced-gradient column (lane 9), per-view records (lane 10)
@@ -430,17 +464,13 @@ __global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) w[k] = isy ? gvv[k] : gsum[k * 16 + 6 + tid];
                     const int col = isy ? a.ycol : a.camcol0 + tid;
+                    chol6_forward(A, w);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        double z = 0.0;
-#pragma unroll
-                        for (int k = 0; k <= i; ++k) z += M[TRI(i, k)] * w[k];
-                        Zv[(size_t)i * a.ZC + col] = z;
-                    }
+                    for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + col] = w[i];
                 }
             } else if (tid == 10) {
 #pragma unroll
-                for (int i = 0; i < 21; ++i) a.Linv[(size_t)21 * v + i] = M[i];
+                for (int i = 0; i < 21; ++i) a.Lfac[(size_t)21 * v + i] = A[i];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     a.Dv[6 * v + i] = Dd[i];
@@ -448,31 +478,20 @@ __global__ void __launch_bounds__(T) k_normal_eq(K2Args a) {
                 }
             }
         }
-        // ---- per-point accumulators (unique point ids inside a view: plain read-modify-write) ----
-        if (active && a.pts_free) {
-            double *pa = accpt + pid * PT_ACC;
-            if (a.cam_free) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) pa[c * 3 + b] += Jc[c] * Jx[b] + Jc[9 + c] * Jx[3 + b];
-            }
-            pa[27] += Jx[0] * Jx[0] + Jx[3] * Jx[3];
-            pa[28] += Jx[0] * Jx[1] + Jx[3] * Jx[4];
-            pa[29] += Jx[0] * Jx[2] + Jx[3] * Jx[5];
-            pa[30] += Jx[1] * Jx[1] + Jx[4] * Jx[4];
-            pa[31] += Jx[1] * Jx[2] + Jx[4] * Jx[5];
-            pa[32] += Jx[2] * Jx[2] + Jx[5] * Jx[5];
-            pa[33] += Jx[0] * r[0] + Jx[3] * r[1];
-            pa[34] += Jx[1] * r[0] + Jx[4] * r[1];
-            pa[35] += Jx[2] * r[0] + Jx[5] * r[1];
-        }
-        __syncthreads();
     }
     // ---- flush the group's accumulators ----
     double *sp = a.slab_pt + (size_t)g * a.P * PT_ACC;
-    if (a.pts_free)
-        for (int e = tid; e < a.P * PT_ACC; e += T) sp[e] = accpt[e];
+    if (a.pts_free) {
+        if (ALIGNED) {
+            // points the group never sees keep the zeros the slab was created with
+            if (v0 < v1 && tid < a.view_off[v0 + 1] - a.view_off[v0]) {
+#pragma unroll
+                for (int i = 0; i < PT_ACC; ++i) sp[pid * PT_ACC + i] = pacc[i];
+            }
+        } else {
+            for (int e = tid; e < a.P * PT_ACC; e += T) sp[e] = accpt[e];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) tiles[wave * 256 + ((lane >> 4) + 4 * i) * 16 + (lane & 15)] = acc_tot[i];
     __syncthreads();
@@ -744,11 +763,11 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
 
 // -----------------------------------------------------------------------------------------
 // K6: back-substitution, one wave per view:
-//   t = Z_v * ds_emb[cam]  (ds_emb has 1 in the y column)   ->  dp = -Linv^T t
+//   t = Z_v * ds_emb[cam]  (ds_emb has 1 in the y column)   ->  dp = -L_v^-T t
 //   candidate pose = pose + dp;  per-view sums for the step evaluation
 // out_view[k][v] (three planes) = dp^T (D dp - g), |dp|^2, |pose|^2
 // -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z, const double *__restrict__ Linv,
+__global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z, const double *__restrict__ Lfac,
                                                    const double *__restrict__ Dv, const double *__restrict__ gv,
                                                    const double *__restrict__ ds_emb,
                                                    const int *__restrict__ cam_of_view,
@@ -771,14 +790,19 @@ __global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) t[i] += __shfl_xor(t[i], off, 64);
     if (lane == 0) {
-        const double *M = Linv + (size_t)21 * v;
+        const double *Lf = Lfac + (size_t)21 * v;     // off-diagonal L, diagonal slots 1 / L_ii
+        double x[6];
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            double s = t[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) s -= Lf[TRI(k, i)] * x[k];
+            x[i] = s * Lf[TRI(i, i)];
+        }
         double m = 0.0, s2 = 0.0, x2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            double dp = 0.0;
-#pragma unroll
-            for (int k = i; k < 6; ++k) dp += M[TRI(k, i)] * t[k];
-            dp = -dp;
+            const double dp = -x[i];
             const double p = poses[6 * v + i];
             poses_cand[6 * v + i] = p + dp;
             if (dposes) dposes[6 * v + i] = dp;
