@@ -211,21 +211,22 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
     double *scal = h->d_E + h->E_scal;
     CVX_HIP(hipMemsetAsync(scal, 0, (2 + 2 * (size_t)h->nranks) * sizeof(double), h->stream));
     {
-        // fixed-order slab sums per camera, then the scalars of this linearisation
-        if (h->pts_free) {
-            const int n_out = h->P * PT_ACC;
-            hipLaunchKernelGGL(k_group_sum, dim3((n_out + 63) / 64, h->C), dim3(256), 0, h->stream, h->d_slab_pt,
-                               (size_t)n_out, n_out, h->d_glist, h->d_glist_off, h->d_Tpt);
-        }
-        hipLaunchKernelGGL(k_group_sum, dim3(4, h->C), dim3(256), 0, h->stream, h->d_slab_cam, (size_t)256, 256,
-                           h->d_glist, h->d_glist_off, h->d_Gcam);
-        if (schur) {
-            const int n_out = h->nblk * 256;
-            hipLaunchKernelGGL(k_group_sum, dim3((n_out + 63) / 64, h->C), dim3(256), 0, h->stream, h->d_slab_tile,
-                               (size_t)n_out, n_out, h->d_clist, h->d_clist_off, h->d_Tt);
-        }
-        hipLaunchKernelGGL(k_lin_scalars, dim3(1), dim3(256), 0, h->stream, h->d_Gcam, h->C, h->d_grp_scal, h->n_groups,
-                           scal, scal + 1, scal + 2 + h->rank, scal + 2 + h->nranks + h->rank);
+        // fixed-order slab sums per camera and the scalars of this linearisation, one launch
+        ReduceArgs ra;
+        ra.njobs = 0; ra.C = h->C;
+        auto add = [&](const double *src, int n_out, const int *list, const int *off, double *dst) {
+            SumJob &j = ra.job[ra.njobs++];
+            j.src = src; j.stride = (size_t)n_out; j.n_out = n_out; j.blocks_x = (n_out + 63) / 64;
+            j.list = list; j.list_off = off; j.dst = dst;
+        };
+        if (schur) add(h->d_slab_tile, h->nblk * 256, h->d_clist, h->d_clist_off, h->d_Tt);
+        if (h->pts_free) add(h->d_slab_pt, h->P * PT_ACC, h->d_glist, h->d_glist_off, h->d_Tpt);
+        add(h->d_slab_cam, 256, h->d_glist, h->d_glist_off, h->d_Gcam);
+        int blocks = 1;
+        for (int i = 0; i < ra.njobs; ++i) blocks += ra.job[i].blocks_x * h->C;
+        ra.slab_cam = h->d_slab_cam; ra.grp_scal = h->d_grp_scal; ra.n_groups = h->n_groups;
+        ra.out_sum = scal; ra.out_bad = scal + 1; ra.out_gmax = scal + 2 + h->rank; ra.out_dmax = scal + 2 + h->nranks + h->rank;
+        hipLaunchKernelGGL(k_reduce_all, dim3(blocks), dim3(256), 0, h->stream, ra);
         CVX_HIP(hipGetLastError());
     }
     if (h->ns > 0) {

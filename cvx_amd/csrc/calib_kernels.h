@@ -610,56 +610,85 @@ __global__ void __launch_bounds__(64 * K3_WAVES) k_schur_syrk(K3Args a) {
 }
 
 // -----------------------------------------------------------------------------------------
-// Slab reductions, fixed order.  k_group_sum: dst[c][e] = sum over the slabs listed for camera c
+// Slab reductions, fixed order.  group_sum_block: dst[c][e] = sum over the slabs listed for camera c
 // of src[slab * stride + e]; a block is 64 consecutive outputs x 4 slices of the list, so every
 // load is a coalesced 512 B row segment and the four partial sums are combined as (0+1)+(2+3).
 // Used for the per-point accumulators (slab_pt -> Tpt[C][P*36]), the per-camera Gram tiles
 // (slab_cam -> Gcam[C][256]) and the Schur tiles (slab_tile -> Tt[C][nblk*256]).
 // -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_group_sum(const double *__restrict__ src, size_t stride, int n_out,
-                                                   const int *__restrict__ list, const int *__restrict__ list_off,
-                                                   double *__restrict__ dst) {
-    __shared__ double part[4][64];
-    const int c = blockIdx.y, lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    const int q0 = list_off[c], q1 = list_off[c + 1];
+struct SumJob {
+    const double *src;
+    size_t stride;
+    int n_out, blocks_x;
+    const int *list, *list_off;
+    double *dst;
+};
+
+struct ReduceArgs {
+    SumJob job[3];
+    int njobs, C;
+    // scalars of the linearisation (done by the last block): sum r^2 = entry 255 of every group's Gram
+    // tile, pose blocks that failed to factor, max |g_pose|, max diag V
+    const double *slab_cam, *grp_scal;
+    int n_groups;
+    double *out_sum, *out_bad, *out_gmax, *out_dmax;
+};
+
+__device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, double (*part)[64]) {
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = bx * 64 + lane;
+    const int q0 = j.list_off[c], q1 = j.list_off[c + 1];
     const int per = (q1 - q0 + 3) >> 2;
     const int a0 = q0 + sl * per, a1 = min(q1, a0 + per);
     double s = 0.0;
-    if (e < n_out)
-        for (int q = a0; q < a1; ++q) s += src[(size_t)list[q] * stride + e];
+    if (e < j.n_out) {
+        int q = a0;
+        for (; q + 8 <= a1; q += 8) {       // eight independent loads in flight
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = j.src[(size_t)j.list[q + u] * j.stride + e];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; q < a1; ++q) s += j.src[(size_t)j.list[q] * j.stride + e];
+    }
     part[sl][lane] = s;
     __syncthreads();
-    if (sl == 0 && e < n_out) dst[(size_t)c * n_out + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (sl == 0 && e < j.n_out) j.dst[(size_t)c * j.n_out + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// scalars of one linearisation (single block): sum r^2 (entry 255 of every camera's Gram tile),
-// number of pose blocks that failed to factor, max |g_pose|, max diag V
-__global__ void __launch_bounds__(256) k_lin_scalars(const double *__restrict__ Gcam, int C,
-                                                     const double *__restrict__ grp_scal, int n_groups,
-                                                     double *out_sum, double *out_bad, double *out_gmax,
-                                                     double *out_dmax) {
-    __shared__ double sh[3][256];
-    double gm = 0.0, dm = 0.0, nb = 0.0;
-    for (int q = threadIdx.x; q < n_groups; q += 256) {
-        gm = fmax(gm, grp_scal[4 * q]);
-        dm = fmax(dm, grp_scal[4 * q + 1]);
-        nb += grp_scal[4 * q + 2];
-    }
-    sh[0][threadIdx.x] = gm; sh[1][threadIdx.x] = dm; sh[2][threadIdx.x] = nb;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            sh[0][threadIdx.x] = fmax(sh[0][threadIdx.x], sh[0][threadIdx.x + off]);
-            sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + off]);
-            sh[2][threadIdx.x] += sh[2][threadIdx.x + off];
+// all slab sums of one linearisation in one launch: blocks [0, sum_j blocks_x_j * C) do the jobs,
+// the last block the scalars
+__global__ void __launch_bounds__(256) k_reduce_all(ReduceArgs a) {
+    __shared__ double part[4][64];
+    int b = blockIdx.x;
+    for (int ji = 0; ji < a.njobs; ++ji) {
+        const int nb = a.job[ji].blocks_x * a.C;
+        if (b < nb) {
+            group_sum_block(a.job[ji], b % a.job[ji].blocks_x, b / a.job[ji].blocks_x, part);
+            return;
         }
-        __syncthreads();
+        b -= nb;
     }
+    double gm = 0.0, dm = 0.0, nb = 0.0, cs = 0.0;
+    for (int q = threadIdx.x; q < a.n_groups; q += 256) {
+        gm = fmax(gm, a.grp_scal[4 * q]);
+        dm = fmax(dm, a.grp_scal[4 * q + 1]);
+        nb += a.grp_scal[4 * q + 2];
+        cs += a.slab_cam[(size_t)q * 256 + 255];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gm = fmax(gm, __shfl_xor(gm, off, 64)); dm = fmax(dm, __shfl_xor(dm, off, 64));
+        nb += __shfl_xor(nb, off, 64); cs += __shfl_xor(cs, off, 64);
+    }
+    if (lane == 0) { part[0][wave] = gm; part[1][wave] = dm; part[2][wave] = nb; part[3][wave] = cs; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int c = 0; c < C; ++c) s += Gcam[(size_t)c * 256 + 255];
-        *out_sum = s; *out_bad = sh[2][0]; *out_gmax = sh[0][0]; *out_dmax = sh[1][0];
+        *a.out_gmax = fmax(fmax(part[0][0], part[0][1]), fmax(part[0][2], part[0][3]));
+        *a.out_dmax = fmax(fmax(part[1][0], part[1][1]), fmax(part[1][2], part[1][3]));
+        *a.out_bad = (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]);
+        *a.out_sum = (part[3][0] + part[3][1]) + (part[3][2] + part[3][3]);
     }
 }
 
