@@ -209,7 +209,6 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
     }
     ph_begin(h, PH_ASSEMBLE);
     double *scal = h->d_E + h->E_scal;
-    CVX_HIP(hipMemsetAsync(scal, 0, (2 + 2 * (size_t)h->nranks) * sizeof(double), h->stream));
     {
         // fixed-order slab sums per camera and the scalars of this linearisation, one launch
         ReduceArgs ra;
@@ -225,7 +224,7 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         int blocks = 1;
         for (int i = 0; i < ra.njobs; ++i) blocks += ra.job[i].blocks_x * h->C;
         ra.slab_cam = h->d_slab_cam; ra.grp_scal = h->d_grp_scal; ra.n_groups = h->n_groups;
-        ra.out_sum = scal; ra.out_bad = scal + 1; ra.out_gmax = scal + 2 + h->rank; ra.out_dmax = scal + 2 + h->nranks + h->rank;
+        ra.scal = scal; ra.rank = h->rank; ra.nranks = h->nranks; ra.fail = h->d_fail;
         hipLaunchKernelGGL(k_reduce_all, dim3(blocks), dim3(256), 0, h->stream, ra);
         CVX_HIP(hipGetLastError());
     }
@@ -325,7 +324,6 @@ private:
         if (st) return st;
         const int ns = h->ns, nxt = 1 - h->cur;
         ph_begin(h, PH_SOLVE);
-        CVX_HIP(hipMemsetAsync(h->d_fail, 0, sizeof(int), h->stream));
         if (ns > 0) {
             cvxs::DampArgs da;
             da.E = h->d_E; da.s2 = h->d_s2sh; da.n = ns; da.npad = h->npad;

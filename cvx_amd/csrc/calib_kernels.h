@@ -631,7 +631,11 @@ struct ReduceArgs {
     // tile, pose blocks that failed to factor, max |g_pose|, max diag V
     const double *slab_cam, *grp_scal;
     int n_groups;
-    double *out_sum, *out_bad, *out_gmax, *out_dmax;
+    // scal = { sum, bad, gmax[nranks], dmax[nranks] }: a rank fills its own max slots and zeroes the
+    // others, so that the sum all-reduce of the exchange delivers every rank's maxima
+    double *scal;
+    int rank, nranks;
+    int *fail;      // factorisation flag of the reduced solve, cleared here for this linear step
 };
 
 __device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, double (*part)[64]) {
@@ -685,10 +689,12 @@ __global__ void __launch_bounds__(256) k_reduce_all(ReduceArgs a) {
     if (lane == 0) { part[0][wave] = gm; part[1][wave] = dm; part[2][wave] = nb; part[3][wave] = cs; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        *a.out_gmax = fmax(fmax(part[0][0], part[0][1]), fmax(part[0][2], part[0][3]));
-        *a.out_dmax = fmax(fmax(part[1][0], part[1][1]), fmax(part[1][2], part[1][3]));
-        *a.out_bad = (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]);
-        *a.out_sum = (part[3][0] + part[3][1]) + (part[3][2] + part[3][3]);
+        for (int q = 0; q < 2 * a.nranks; ++q) a.scal[2 + q] = 0.0;
+        a.scal[2 + a.rank] = fmax(fmax(part[0][0], part[0][1]), fmax(part[0][2], part[0][3]));
+        a.scal[2 + a.nranks + a.rank] = fmax(fmax(part[1][0], part[1][1]), fmax(part[1][2], part[1][3]));
+        a.scal[1] = (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]);
+        a.scal[0] = (part[3][0] + part[3][1]) + (part[3][2] + part[3][3]);
+        *a.fail = 0;
     }
 }
 
