@@ -209,7 +209,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes")
             except Exception:
                 traffic = None
         out = {
