@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=400, help="views per camera of the CPU sample")
+    ap.add_argument("--cpu-views", type=int, default=1250, help="views per camera of the CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--host-exchange", action="store_true", help="all-reduce host copies instead of device buffers")
     a = ap.parse_args()

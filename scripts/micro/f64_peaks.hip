@@ -22,6 +22,85 @@ __global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double see
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
+template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma4(double *out, int iters, double seed) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0;
+    double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// the inner loop shape of k_schur_syrk: per block one A, one B, three DPP rotations, four MFMAs
+template <int MODE>   // 0: registers only, 1: + DPP rotations, 2: + LDS operand reads
+__global__ void __launch_bounds__(768) k_syrk_shape(double *out, int iters, double seed) {
+    __shared__ double lds[16 * 336];
+    for (int i = threadIdx.x; i < 16 * 336; i += 768) lds[i] = seed + i * 1e-6;
+    __syncthreads();
+    double acc[10][4];
+    for (int i = 0; i < 10; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0;
+    const int lane = threadIdx.x & 63, kq = lane >> 4, cq = lane & 15;
+    double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+        const double *p = lds + ((it & 3) * 4 + kq) * 336 + cq;
+        double pa[10], pb[10];
+        if (MODE >= 2) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { pa[i] = p[16 * i]; pb[i] = p[16 * (i + 5)]; }
+        }
+        if (MODE == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            double av = a, b0 = b;
+            if (MODE >= 2) { av = pa[i]; b0 = pb[i]; }
+            acc[i][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, MODE ? row_ror_f64<4>(b0) : b0, acc[i][1], 0, 0, 0);
+            acc[i][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, MODE ? row_ror_f64<8>(b0) : b0, acc[i][2], 0, 0, 0);
+            acc[i][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, MODE ? row_ror_f64<12>(b0) : b0, acc[i][3], 0, 0, 0);
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 10; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// MFMA waves and VALU waves side by side: blockIdx parity picks the role
+__global__ void __launch_bounds__(256) k_mix(double *out, int iters, double seed) {
+    double s = 0;
+    if (blockIdx.x & 1) {
+        f64x4 acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = f64x4{0, 0, 0, 0};
+        double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double x[8];
+        for (int i = 0; i < 8; ++i) x[i] = seed + i + threadIdx.x * 1e-6;
+        const double m = 1.0000001, c = 1e-9;
+        for (int it = 0; it < iters * 16; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = __builtin_fma(x[i], m, c);
+        }
+        for (int i = 0; i < 8; ++i) s += x[i];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(256) k_fma(double *out, int iters, double seed) {
     double x[8];
     for (int i = 0; i < 8; ++i) x[i] = seed + i + threadIdx.x * 1e-6;
@@ -99,6 +178,30 @@ int main() {
         ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<9>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, 5);
         flops = (double)blocks * 4 * iters * 9 * 2048.0;
         printf("mfma_f64_16x16x4 x9acc  %d wave/SIMD: %.3f ms  %.2f TFLOP/s\n", wps, ms, flops / ms / 1e9);
+    }
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        int blocks = 256 * wps;
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_mfma4<8>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, 5);
+        double flops = (double)blocks * 4 * iters * 8 * 512.0;
+        printf("mfma_f64_4x4x4_4b x8acc  %d wave/SIMD: %.3f ms  %.2f TFLOP/s\n", wps, ms, flops / ms / 1e9);
+    }
+    {   // k_schur_syrk's inner loop shape, 12 waves per CU
+        const int it2 = 2000;
+        double flops = 256.0 * 12 * it2 * 40 * 512.0;
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_syrk_shape<0>), dim3(256), dim3(768), 0, 0, out, it2, 1.0); }, 5);
+        printf("syrk shape, registers only: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_syrk_shape<1>), dim3(256), dim3(768), 0, 0, out, it2, 1.0); }, 5);
+        printf("syrk shape, + DPP rotations: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_syrk_shape<2>), dim3(256), dim3(768), 0, 0, out, it2, 1.0); }, 5);
+        printf("syrk shape, + DPP + LDS operands: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_syrk_shape<3>), dim3(256), dim3(768), 0, 0, out, it2, 1.0); }, 5);
+        printf("syrk shape, + DPP + LDS operands, all 20 reads then wait: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+    }
+    {   // 2 MFMA waves + 2 VALU waves per SIMD
+        int blocks = 256 * 4;
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, 5);
+        double fm = (double)(blocks / 2) * 4 * iters * 8 * 2048.0, fv = (double)(blocks / 2) * 256 * iters * 16.0 * 8 * 2.0;
+        printf("mixed 2 MFMA + 2 VALU waves/SIMD: %.3f ms  MFMA %.2f + VALU %.2f = %.2f TFLOP/s\n", ms, fm / ms / 1e9, fv / ms / 1e9, (fm + fv) / ms / 1e9);
     }
     {   // in-kernel clock and cycles per MFMA (one wave's view), long enough for DVFS to settle
         long long *clk; CK(hipMalloc(&clk, 16)); long long h[2];
