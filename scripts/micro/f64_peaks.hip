@@ -76,6 +76,44 @@ __global__ void __launch_bounds__(768) k_syrk_shape(double *out, int iters, doub
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// how the LDS-fed rate depends on the number and width of operand reads per 40 MFMAs
+template <int NREAD, bool WIDE>
+__global__ void __launch_bounds__(768) k_syrk_reads(double *out, int iters, double seed) {
+    __shared__ double lds[16 * 336];
+    for (int i = threadIdx.x; i < 16 * 336; i += 768) lds[i] = seed + i * 1e-6;
+    __syncthreads();
+    double acc[10][4];
+    for (int i = 0; i < 10; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0;
+    const int lane = threadIdx.x & 63, kq = lane >> 4, cq = lane & 15;
+    for (int it = 0; it < iters; ++it) {
+        double v[20];
+        if (WIDE) {
+            const double2 *p = (const double2 *)(lds + ((it & 3) * 4 + kq) * 336) + cq;
+#pragma unroll
+            for (int i = 0; i < NREAD; ++i) { const double2 t = p[16 * i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+#pragma unroll
+            for (int i = 2 * NREAD; i < 20; ++i) v[i] = v[i % (2 * NREAD)];
+        } else {
+            const double *p = lds + ((it & 3) * 4 + kq) * 336 + cq;
+#pragma unroll
+            for (int i = 0; i < NREAD; ++i) v[i] = p[16 * i];
+#pragma unroll
+            for (int i = NREAD; i < 20; ++i) v[i] = v[i % NREAD];
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const double av = v[i], b0 = v[10 + i];
+            acc[i][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, row_ror_f64<4>(b0), acc[i][1], 0, 0, 0);
+            acc[i][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, row_ror_f64<8>(b0), acc[i][2], 0, 0, 0);
+            acc[i][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, row_ror_f64<12>(b0), acc[i][3], 0, 0, 0);
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 10; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // MFMA waves and VALU waves side by side: blockIdx parity picks the role
 __global__ void __launch_bounds__(256) k_mix(double *out, int iters, double seed) {
     double s = 0;
@@ -196,6 +234,13 @@ int main() {
         printf("syrk shape, + DPP + LDS operands: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
         ms = time_ms([&] { hipLaunchKernelGGL((k_syrk_shape<3>), dim3(256), dim3(768), 0, 0, out, it2, 1.0); }, 5);
         printf("syrk shape, + DPP + LDS operands, all 20 reads then wait: %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+    }
+    {
+        const int it2 = 2000;
+        double flops = 256.0 * 12 * it2 * 40 * 512.0;
+#define RUNR(N, W) { float ms = time_ms([&] { hipLaunchKernelGGL((k_syrk_reads<N, W>), dim3(256), dim3(768), 0, 0, out, it2, 1.0); }, 5); \
+        printf("syrk reads: %2d x %s per 40 MFMA: %.3f ms  %.2f TFLOP/s\n", N, W ? "b128" : "b64 ", ms, flops / ms / 1e9); }
+        RUNR(20, false) RUNR(12, false) RUNR(7, false) RUNR(4, false) RUNR(2, false) RUNR(10, true) RUNR(6, true) RUNR(4, true)
     }
     {   // 2 MFMA waves + 2 VALU waves per SIMD
         int blocks = 256 * 4;
