@@ -20,7 +20,7 @@ constexpr int TB = 32;
 
 // -----------------------------------------------------------------------------------------
 // A (npad x npad, row-major) = [ S + D  .  ] rows/cols < n
-//                              [ -g_red 1 ] row n (the right-hand side), identity beyond
+//                              [ -g_red c ] row n (the right-hand side; c = 1e300), identity beyond
 // D_j = clamp(s_j^2 d_j, min_diag, max_diag) * inv_radius / s_j^2 + mu,  d_j = U_jj
 // -----------------------------------------------------------------------------------------
 struct DampArgs {
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_damp_prepare(DampArgs a) {
     } else if (i == n && j < n) {
         v = -a.E[(size_t)n * n + j];
     } else if (i == j) {
-        v = 1.0;
+        v = (i == n) ? 1e300 : 1.0;     // keeps the right-hand-side row's pivot positive whatever |y|^2 is
     }
     a.A[t] = v;
 }
@@ -78,7 +78,8 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 // the triangular solve rides along for free.  Then all four waves update A_ij -= L_ik L_jk^T with
 // MFMA.  Panel k of A is only read in this launch; factor tiles go to the separate array L (block
 // 0 the diagonal tile, the blocks with tj == k + 1 their L_ik): no block reads what another writes.
-// Rows with global index >= n (the right-hand-side row and the padding) take diagonal 1.
+// Rows with global index >= n (the right-hand-side row and the padding) need no special case: k_damp_prepare
+// gives them diagonal 1e300 and 1.
 // -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld, int n, int k, int nT, int *fail) {
     __shared__ double D[2][TB][TB + 1];
@@ -118,6 +119,10 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
     __syncthreads();
     CSTAMP(1);
     if (wave < 2) {
+        // left-looking column loop, software-pipelined: while column j is being finished (its diagonal ->
+        // rsqrt -> scale chain), the dot product of column j + 1 over every term but the newest is already
+        // accumulated from LDS broadcasts of pivot row j + 1 (all published at least one column earlier);
+        // the newest term, L[j+1][j], travels by readlane.  The LDS round trip is off the serial chain.
         const int r = lane & 31;
         const bool panel = lane >= 32;
         double (*Dw)[TB + 1] = D[wave];
@@ -125,24 +130,37 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
         bool bad = false;
 #pragma unroll
         for (int c = 0; c < TB; ++c) row[c] = panel ? P[wave][r][c] : Dw[r][c];
+        double tpart = row[0];      // row[j] - sum_{m <= j-2} L[r][m] L[j][m]
+        double valprev = 0.0;
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
-            double t0 = row[j], t1 = 0.0;
-#pragma unroll
-            for (int m = 0; m < j; ++m) {
-                const double ljm = Dw[j][m];
-                if (m & 1) t1 = fma(row[m], ljm, t1); else t0 = fma(-row[m], ljm, t0);
-            }
-            const double t = t0 - t1;
+            double t = tpart;
+            if (j > 0) t = fma(-valprev, readlane_f64(valprev, j), t);
             const double d = readlane_f64(t, j);
-            const bool special = (k * TB + j) >= n;
-            bad = bad || (!special && !(d > 0.0 && d < 1.7e308));
-            const double ri = special ? 1.0 : rsqrt(d);
-            const double val = (lane == j) ? (special ? 1.0 : d * ri) : t * ri;
+            if (j + 1 < TB) {       // independent of this column's result
+                double pl[TB];      // pivot row j + 1, every read issued before the first use
+#pragma unroll
+                for (int m = 0; m < j; ++m) pl[m] = Dw[j + 1][m];
+                double t0 = row[j + 1], t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                for (int m = 0; m < j; ++m) {
+                    if ((m & 3) == 0) t0 = fma(-row[m], pl[m], t0);
+                    else if ((m & 3) == 1) t1 = fma(row[m], pl[m], t1);
+                    else if ((m & 3) == 2) t2 = fma(row[m], pl[m], t2);
+                    else t3 = fma(row[m], pl[m], t3);
+                }
+                tpart = (t0 - t1) - (t2 + t3);
+            }
+            // 1 / sqrt(d): hardware estimate + one Newton-Raphson step of third order (no special-case
+            // handling: d <= 0 or non-finite gives NaN, which the flag below reports)
+            bad = bad || !(d > 0.0 && d < 1.7e308);
+            const double y0 = __builtin_amdgcn_rsq(d);
+            const double e = fma(-d * y0, y0, 1.0);
+            const double ri = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+            const double val = t * ri;      // the diagonal lane has t == d: val = sqrt(d)
             row[j] = val;
-            __builtin_amdgcn_wave_barrier();
+            valprev = val;
             if (!panel) Dw[r][j] = val;
-            __builtin_amdgcn_wave_barrier();
         }
         if (panel) {
 #pragma unroll
