@@ -182,6 +182,29 @@ def main():
         eval_ms = e0.elapsed_time(e1) / n_eval
         g.close()
 
+    # ---- BASELINE config 2: hand-eye AX = XB refinement, 200 poses (launch-latency-bound by construction:
+    #      SURVEY.md 8d asks for time per LM iteration only) ----
+    handeye = None
+    if rank == 0:
+        handeye = {}
+        for name, moving in (("fixed_camera_all_pairs", False), ("moving_camera_consecutive_pairs", True)):
+            G, T, xgt, x0 = cvx_amd.synth_handeye(200, 20260002, moving=moving)
+            A, B = cvx_amd.handeye_pairs(G, T, moving=moving)
+            he = cvx_amd.HandEye(*cvx_amd.pairs_to_quat_trans(A, B), device=local_rank)
+            ho = capi.options("handeye")
+            ho.function_tolerance = ho.gradient_tolerance = ho.parameter_tolerance = -1.0
+            ho.max_iterations = 20
+            he.solve(x0, ho)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                p, hs = he.solve(x0, ho)
+            torch.cuda.synchronize()
+            handeye[name] = {"pairs": int(len(A)), "ms_per_lm_iteration": 1e3 * (time.perf_counter() - th) / (reps * max(hs.iterations, 1)),
+                             "iterations_per_solve": hs.iterations, "final_cost": hs.final_cost}
+            he.close()
+
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -244,6 +267,7 @@ def main():
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": EVAL_BYTES_PER_OBS * N / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
+        out["handeye"] = handeye
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_views, a.cpu_iters)
         print(json.dumps(out), flush=True)
