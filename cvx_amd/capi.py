@@ -120,6 +120,7 @@ SIGNATURES = {
     "cvx_quat_trans_to_affine": (None, [dp, dp]),
     "cvx_handeye_pairs_fixed": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
     "cvx_handeye_pairs_moving": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
+    "cvx_handeye_linear": (C.c_int, [C.c_int, C.c_int, dp, dp, dp]),
     "cvx_synth_calib_count": (C.c_int64, [C.POINTER(SynthCalibSpec)]),
     "cvx_synth_calib": (C.c_int, [C.POINTER(SynthCalibSpec), ip, ip, ip, dp, dp, dp, dp, dp, dp, dp, dp]),
     "cvx_synth_handeye": (C.c_int, [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp]),

@@ -195,6 +195,15 @@ def handeye_pairs(G, T, moving=False):
     return A[:cnt.value], B[:cnt.value]
 
 
+def handeye_linear(A, B, method=0):
+    """Closed-form initial X (4x4 column-major flat) from motion pairs: 0 dual quaternion, 1 Tsai, 2 Horaud
+    (handeye.cpp:335-599)."""
+    A, B = f64(A), f64(B)
+    X = np.zeros(16)
+    check(lib().cvx_handeye_linear(int(method), A.shape[0], pd(A), pd(B), pd(X)), "handeye_linear")
+    return X
+
+
 def pairs_to_quat_trans(A, B):
     n = A.shape[0]
     qa = np.zeros((n, 4)); ta = np.zeros((n, 3)); qb = np.zeros((n, 4)); tb = np.zeros((n, 3))

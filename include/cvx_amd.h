@@ -235,6 +235,13 @@ int cvx_handeye_pairs_fixed(int n, const double *gripper_to_base, const double *
 int cvx_handeye_pairs_moving(int n, const double *gripper_to_base, const double *target_to_sensor,
                              double *A, double *B, int cap, int *n_pairs);
 
+/* closed-form initial estimate of X from motion pairs A_i X = X B_i (n column-major 4x4 each), the step
+ * solveFixed / solveMoving run before solveNonLinear (handeye.cpp:697-702, 750-755):
+ * method 0 dual quaternions, Daniilidis (handeye.cpp:335-473; Parameters::method_ default, handeye.hpp:16),
+ * method 1 Tsai (handeye.cpp:475-533; needs n > 2), method 2 Horaud-Dornaika (handeye.cpp:537-599).
+ * Host only.  X: column-major 4x4. */
+int cvx_handeye_linear(int method, int n, const double *A, const double *B, double X[16]);
+
 /* ------------------------------------------------------------------------ */
 /* Synthetic workloads of SURVEY.md section 8(d) (host only, deterministic)  */
 /* ------------------------------------------------------------------------ */

@@ -172,13 +172,14 @@ bool solve_nonlinear(const std::vector<Affine> &A, const std::vector<Affine> &B,
     return true;
 }
 
-// The refinement half of HandEyeCalibration::solveFixed / solveMoving (handeye.cpp:665-764):
-// builds the motion pairs exactly as the reference does and refines X, which must hold the
-// linear initial estimate on entry (the closed-form initialisers, handeye.cpp:335-599, are
-// outside the accelerated path -- SURVEY.md 8f).
+// HandEyeCalibration::solveFixed / solveMoving (handeye.cpp:665-764) in full: motion pairs exactly as the
+// reference builds them, the closed-form initial estimate selected by `method` (HandEyeCalibration::Method:
+// 0 DualQuaternion -- the default, handeye.hpp:16 --, 1 Tsai, 2 Horaud; handeye.cpp:335-599) and, when
+// `refine` (Parameters::refine_, default true), solveNonLinear on the GPU.  X is output only.
 template <class Affine>
 bool solve_handeye(const std::vector<Affine> &gripper_to_base, const std::vector<Affine> &target_to_sensor,
-                   Affine &X, bool moving, int device = 0, void *stream = nullptr) {
+                   Affine &X, bool moving, int method = 0, bool refine = true, int device = 0,
+                   void *stream = nullptr) {
     const int n = (int)gripper_to_base.size();
     if ((int)target_to_sensor.size() != n || n < 2) return false;
     std::vector<double> G(16 * (size_t)n), T(16 * (size_t)n);
@@ -191,8 +192,14 @@ bool solve_handeye(const std::vector<Affine> &gripper_to_base, const std::vector
     auto pairs = moving ? cvx_handeye_pairs_moving : cvx_handeye_pairs_fixed;
     int cnt = 0;
     check(pairs(n, G.data(), T.data(), nullptr, nullptr, 0, &cnt), "pair count");
-    std::vector<double> A(16 * (size_t)(cnt ? cnt : 1)), B(A.size());
+    if (cnt < 1) return false;
+    std::vector<double> A(16 * (size_t)cnt), B(A.size());
     check(pairs(n, G.data(), T.data(), A.data(), B.data(), cnt, &cnt), "pairs");
+    double X0[16];
+    if (cvx_handeye_linear(method, cnt, A.data(), B.data(), X0) != CVX_OK) return false;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) X.matrix()(r, c) = X0[4 * c + r];
+    if (!refine) return true;
     std::vector<Affine> Av(cnt, X), Bv(cnt, X);
     for (int i = 0; i < cnt; ++i)
         for (int c = 0; c < 4; ++c)

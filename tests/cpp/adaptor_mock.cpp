@@ -78,10 +78,10 @@ int main() {
     std::vector<Mat4> Gv(n), Tv(n);
     for (int i = 0; i < n; ++i) for (int k = 0; k < 16; ++k) { Gv[i].m[k] = G[16 * i + k]; Tv[i].m[k] = T[16 * i + k]; }
     Mat4 X;
-    cvx_quat_trans_to_affine(x0, X.m);
+    for (int k = 0; k < 16; ++k) X.m[k] = 0;
     bool ok;
     try {
-        ok = cvx_amd::solve_handeye(Gv, Tv, X, false);
+        ok = cvx_amd::solve_handeye(Gv, Tv, X, false);      // dual-quaternion estimate + GPU refinement
     } catch (const std::exception &e) {
         std::fprintf(stderr, "%s\n", e.what());
         return 5;

@@ -52,9 +52,11 @@ def test_adaptor_refine_and_handeye_match_oracle(orc):
     G, T, xgt, x0 = cvx_amd.synth_handeye(30, 20260002)
     A, B = cvx_amd.handeye_pairs(G, T)
     ho = orc.HandEye(*cvx_amd.pairs_to_quat_trans(A, B))
-    # the adaptor converts X0 to a matrix and back to a quaternion before solving
-    M = np.zeros(16); q = np.zeros(4); t = np.zeros(3)
-    L.cvx_quat_trans_to_affine(cvx_amd.capi.pd(x0.copy()), cvx_amd.capi.pd(M))
+    # the adaptor starts from the dual-quaternion closed form (the reference's default method), then
+    # converts that matrix to a quaternion before refining
+    from oracle import handeye_init as hi
+    X0 = hi.linear_dual_quaternion([np.asarray(m).reshape(4, 4).T for m in A], [np.asarray(m).reshape(4, 4).T for m in B])
+    M = np.ascontiguousarray(X0.T).reshape(-1).copy(); q = np.zeros(4); t = np.zeros(3)
     L.cvx_affine_to_quat_trans(cvx_amd.capi.pd(M), cvx_amd.capi.pd(q), cvx_amd.capi.pd(t))
     p, hs = ho.solve(np.concatenate([q, t]), orc.options("handeye"))
     L.cvx_quat_trans_to_affine(cvx_amd.capi.pd(p.copy()), cvx_amd.capi.pd(M))
