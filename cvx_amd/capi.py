@@ -121,6 +121,17 @@ SIGNATURES = {
     "cvx_handeye_pairs_fixed": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
     "cvx_handeye_pairs_moving": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
     "cvx_handeye_linear": (C.c_int, [C.c_int, C.c_int, dp, dp, dp]),
+    "cvx_calib_data_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "cvx_calib_data_free": (None, [C.c_void_p]),
+    "cvx_calib_data_info": (C.c_int, [C.c_void_p, ip, ip, ip, ip, C.POINTER(C.c_int64)]),
+    "cvx_calib_data_copy": (C.c_int, [C.c_void_p, dp, ip, ip, dp, dp]),
+    "cvx_calib_data_path": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "cvx_calib_data_save": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, dp, C.c_int,
+                                      C.POINTER(C.c_char_p), ip, ip, dp, dp]),
+    "cvx_camera_yaml_read": (C.c_int, [C.c_char_p, ip, ip, dp, dp]),
+    "cvx_camera_yaml_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, dp, dp]),
+    "cvx_robot_config_read": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, dp, dp]),
+    "cvx_robot_config_write_launch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, dp]),
     "cvx_synth_calib_count": (C.c_int64, [C.POINTER(SynthCalibSpec)]),
     "cvx_synth_calib": (C.c_int, [C.POINTER(SynthCalibSpec), ip, ip, ip, dp, dp, dp, dp, dp, dp, dp, dp]),
     "cvx_synth_handeye": (C.c_int, [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp]),

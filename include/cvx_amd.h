@@ -243,6 +243,43 @@ int cvx_handeye_pairs_moving(int n, const double *gripper_to_base, const double 
 int cvx_handeye_linear(int method, int n, const double *A, const double *B, double X[16]);
 
 /* ------------------------------------------------------------------------ */
+/* On-disk formats either side of the path (host only)   */
+/* ------------------------------------------------------------------------ */
+/* CameraCalibration::Data::load (calibration.cpp:49-79): "w h", n_coords + "x y z" lines, n_views, then per
+ * view image_path (one whitespace-free token), n_markers and "x y id" lines.  Values are read as float
+ * (cv::Point3f / Point2f) and handed out as double in the flat layout cvx_calib_desc uses. */
+typedef struct cvx_calib_data cvx_calib_data;
+int cvx_calib_data_load(const char *path, cvx_calib_data **out);
+void cvx_calib_data_free(cvx_calib_data *d);
+int cvx_calib_data_info(const cvx_calib_data *d, int *width, int *height, int *n_coords, int *n_views,
+                        int64_t *n_obs);
+/* coords[n_coords*3], view_off[n_views+1], point_id/obs_x/obs_y[n_obs]; any may be NULL */
+int cvx_calib_data_copy(const cvx_calib_data *d, double *coords, int *view_off, int *point_id, double *obs_x,
+                        double *obs_y);
+const char *cvx_calib_data_path(const cvx_calib_data *d, int view);   /* valid until cvx_calib_data_free */
+/* CameraCalibration::Data::save (calibration.cpp:22-47): same text, floats at the stream's default precision */
+int cvx_calib_data_save(const char *path, int width, int height, int n_coords, const double *coords,
+                        int n_views, const char *const *image_paths, const int *view_off,
+                        const int *point_id, const double *obs_x, const double *obs_y);
+
+/* PinholeCamera::read / write (camera.hpp:138-180): YAML keys image_width, image_height, camera_matrix and
+ * distortion_coefficients, matrices as {rows, cols, data} in row-major order (camera.hpp:19-72).
+ * K = {fx, fy, cx, cy}; dist = OpenCV order {k1, k2, p1, p2, k3}. */
+int cvx_camera_yaml_read(const char *path, int *width, int *height, double K[4], double dist[5]);
+int cvx_camera_yaml_write(const char *path, int width, int height, const double K[4], const double dist[5]);
+
+/* CameraRobotConfiguration::readRobotConfiguration (configuration.hpp:44-91).  Frame names are copied into
+ * buffers of `cap` bytes; initial_cam is the column-major 4x4 Translation(x,y,z) * q.normalized(); when the
+ * q* keys are absent, roll/pitch/yaw are accepted as Rx(roll) Ry(pitch) Rz(yaw) (the form the reference's
+ * sample scripts/configuration.yaml uses). */
+int cvx_robot_config_read(const char *path, char *base_frame, char *tool_frame, char *camera_frame, size_t cap,
+                          double base_to_tag[3], double initial_cam[16]);
+/* CameraRobotConfiguration::writeCameraTranformationToFile (configuration.hpp:31-43): ROS launch file with
+ * one static_transform_publisher "x y z qx qy qz qw tool camera 100" */
+int cvx_robot_config_write_launch(const char *path, const char *tool_frame, const char *camera_frame,
+                                  const double X_colmajor[16]);
+
+/* ------------------------------------------------------------------------ */
 /* Synthetic workloads of SURVEY.md section 8(d) (host only, deterministic)  */
 /* ------------------------------------------------------------------------ */
 typedef struct {
