@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libcvx_amd.so")
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
+fp = C.POINTER(C.c_float)
 TRACE_MAX = 1024
 RCCL_ID_BYTES = 128
 
@@ -121,6 +122,12 @@ SIGNATURES = {
     "cvx_handeye_pairs_fixed": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
     "cvx_handeye_pairs_moving": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
     "cvx_handeye_linear": (C.c_int, [C.c_int, C.c_int, dp, dp, dp]),
+    "cvx_homography_create": (C.c_int, [C.c_int, ip, fp, fp, fp, fp, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cvx_homography_destroy": (None, [C.c_void_p]),
+    "cvx_homography_solve": (C.c_int, [C.c_void_p, dp, C.c_int, dp, dp, ip]),
+    "cvx_homography_set": (C.c_int, [C.c_void_p, dp]),
+    "cvx_homography_run": (C.c_int, [C.c_void_p, C.c_int, dp]),
+    "cvx_homography_get": (C.c_int, [C.c_void_p, dp, dp, ip]),
     "cvx_calib_data_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "cvx_calib_data_free": (None, [C.c_void_p]),
     "cvx_calib_data_info": (C.c_int, [C.c_void_p, ip, ip, ip, ip, C.POINTER(C.c_int64)]),

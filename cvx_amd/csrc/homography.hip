@@ -1,0 +1,124 @@
+// Batched homography refinement: handle + C ABI around k_homography_lm.
+// Replaces HomographyEstimator::solveLM (/root/reference/modules/calib/src/homography.cpp:218-236) for many
+// independent views at once.
+#include <cfloat>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "homography_kernels.h"
+
+using namespace cvxhom;
+
+struct cvx_homography {
+    int n = 0, device = 0, max_points = 0;
+    long long total = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int *d_off = nullptr, *d_ret = nullptr;
+    float *d_pts = nullptr;          // x1 | y1 | x2 | y2, `total` each
+    double *d_H = nullptr, *d_info = nullptr;
+    size_t lds_bytes = 0;
+    ~cvx_homography() {
+        (void)hipSetDevice(device);
+        for (void *p : {(void *)d_off, (void *)d_ret, (void *)d_pts, (void *)d_H, (void *)d_info})
+            if (p) (void)hipFree(p);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int cvx_homography_create(int n_problems, const int *off, const float *x1, const float *y1,
+                                     const float *x2, const float *y2, int device, void *stream,
+                                     cvx_homography **out) {
+    if (!out) return CVX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_problems <= 0 || !off || off[0] != 0) { cvx::set_last_error("homography: need n_problems > 0 and off[0] == 0"); return CVX_ERR_INVALID_ARG; }
+    int max_points = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const int c = off[i + 1] - off[i];
+        if (c < 0) { cvx::set_last_error("homography: offsets must not decrease"); return CVX_ERR_INVALID_ARG; }
+        if (c > max_points) max_points = c;
+    }
+    const long long total = off[n_problems];
+    if (total > 0 && (!x1 || !y1 || !x2 || !y2)) return CVX_ERR_INVALID_ARG;
+    if (max_points > CVX_HOMOGRAPHY_MAX_POINTS) {
+        cvx::set_last_error("homography: more than CVX_HOMOGRAPHY_MAX_POINTS point pairs in one problem");
+        return CVX_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { cvx::set_last_error("no HIP device"); return CVX_ERR_NO_DEVICE; }
+    CVX_HIP(hipSetDevice(device));
+    std::unique_ptr<cvx_homography> h(new cvx_homography);
+    h->n = n_problems; h->device = device; h->max_points = max_points; h->total = total;
+    if (stream) h->stream = (hipStream_t)stream;
+    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    h->lds_bytes = hom_lds_doubles(max_points < 4 ? 4 : max_points) * sizeof(double);
+    const size_t tp = (size_t)(total > 0 ? total : 1);
+    CVX_HIP(hipMalloc(&h->d_off, sizeof(int) * (n_problems + 1)));
+    CVX_HIP(hipMalloc(&h->d_ret, sizeof(int) * n_problems));
+    CVX_HIP(hipMalloc(&h->d_pts, sizeof(float) * 4 * tp));
+    CVX_HIP(hipMalloc(&h->d_H, sizeof(double) * 9 * n_problems));
+    CVX_HIP(hipMalloc(&h->d_info, sizeof(double) * 10 * n_problems));
+    CVX_HIP(hipMemcpyAsync(h->d_off, off, sizeof(int) * (n_problems + 1), hipMemcpyHostToDevice, h->stream));
+    if (total > 0) {
+        const float *src[4] = {x1, y1, x2, y2};
+        for (int k = 0; k < 4; ++k)
+            CVX_HIP(hipMemcpyAsync(h->d_pts + k * tp, src[k], sizeof(float) * total, hipMemcpyHostToDevice, h->stream));
+    }
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    *out = h.release();
+    return CVX_OK;
+}
+
+extern "C" void cvx_homography_destroy(cvx_homography *h) { delete h; }
+
+extern "C" int cvx_homography_set(cvx_homography *h, const double *H) {
+    if (!h || !H) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    CVX_HIP(hipMemcpyAsync(h->d_H, H, sizeof(double) * 9 * h->n, hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+// launches the batch on the handle's stream and waits for it
+extern "C" int cvx_homography_run(cvx_homography *h, int max_iter, const double *opts) {
+    if (!h || max_iter < 0) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    const size_t tp = (size_t)(h->total > 0 ? h->total : 1);
+    HomArgs a;
+    a.off = h->d_off;
+    a.x1 = h->d_pts; a.y1 = h->d_pts + tp; a.x2 = h->d_pts + 2 * tp; a.y2 = h->d_pts + 3 * tp;
+    a.H = h->d_H; a.info = h->d_info; a.ret = h->d_ret;
+    a.n_problems = h->n; a.itmax = max_iter;
+    // LMSolver::minimizeDer (lm.hpp:61): {factor_, g_tol_, x_tol_, g_tol_} = {1e-3, eps, eps, eps}
+    a.tau = opts ? opts[0] : 1e-3;
+    a.eps1 = opts ? opts[1] : DBL_EPSILON;
+    a.eps2 = opts ? opts[2] : DBL_EPSILON;
+    a.eps3 = opts ? opts[3] : DBL_EPSILON;
+    CVX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_homography_lm),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    hipLaunchKernelGGL(k_homography_lm, dim3(h->n), dim3(64), h->lds_bytes, h->stream, a);
+    CVX_HIP(hipGetLastError());
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+extern "C" int cvx_homography_get(cvx_homography *h, double *H, double *info, int *ret) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    if (H) CVX_HIP(hipMemcpyAsync(H, h->d_H, sizeof(double) * 9 * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (info) CVX_HIP(hipMemcpyAsync(info, h->d_info, sizeof(double) * 10 * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (ret) CVX_HIP(hipMemcpyAsync(ret, h->d_ret, sizeof(int) * h->n, hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+extern "C" int cvx_homography_solve(cvx_homography *h, double *H, int max_iter, const double *opts, double *info,
+                                    int *ret) {
+    int st = cvx_homography_set(h, H);
+    if (st) return st;
+    st = cvx_homography_run(h, max_iter, opts);
+    if (st) return st;
+    return cvx_homography_get(h, H, info, ret);
+}

@@ -1,0 +1,304 @@
+// Batched homography refinement on gfx950: one LM problem (8 parameters, 2N residuals) per 64-lane wave.
+// Path: HomographyEstimator::solveLM (/root/reference/modules/calib/src/homography.cpp:159-236) =
+// LMHomographyEstimator::errors / jacobian (:166-207) driven by levmar's dlevmar_der
+// (modules/util/src/3rdparty/levmar/lm_core.c:60-423) through LMSolver::minimizeDer (lm.hpp:60-64), with the
+// no-LAPACK LU solve (Axb_core.c:992-1139).
+//
+// Every floating-point sum is evaluated in the reference's order (the row order and 32-row blocking of
+// lm_core.c:217-255 / misc_core.c:80-132, the four interleaved chains of misc_core.c:712-798, Crout LU with
+// implicit-scaling pivoting), so a problem's iterates are bit-identical to the CPU reference's; parallelism
+// comes from one lane per normal-equation entry (29 distinct sums because of the Jacobian's block structure),
+// the 8x8 system held one entry per lane, and thousands of independent problems in flight.
+#pragma once
+#include <cfloat>
+
+#include "common.h"
+
+namespace cvxhom {
+
+struct HomArgs {
+    const int *off;                         // [n_problems + 1] offsets into the point arrays
+    const float *x1, *y1, *x2, *y2;         // gathered point pairs (cv::Point2f)
+    double *H;                              // [n_problems][9] row-major, in/out
+    double *info;                           // [n_problems][10] levmar info[] (may be null)
+    int *ret;                               // [n_problems] dlevmar_der return value (may be null)
+    int n_problems, itmax;
+    double tau, eps1, eps2, eps3;           // opts[0..3] as lm.hpp:61 builds them
+};
+
+constexpr int HOM_SCRATCH = 32;                                   // doubles of per-wave exchange space
+__host__ __device__ inline size_t hom_lds_doubles(int n_points) { return (size_t)13 * n_points + HOM_SCRATCH; }
+
+__device__ __forceinline__ double bcast(double v, int lane /* wave-uniform */) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Which products lane L sums.  Per point the Jacobian rows are (homography.cpp:204-205)
+//   even row: a0 a1 a2 0 0 0 b00 b01      odd row: 0 0 0 a0 a1 a2 b10 b11
+// stored as Q[pt] = {a0, a1, a2, b00, b01, b10, b11, e_even, e_odd}.  {c0, d0} = columns of Q multiplied for the
+// even row's term, {c1, d1} for the odd row's, -1 = structurally zero.  Lanes 0-20: the distinct entries of
+// J^T J; lanes 21-28: J^T e.
+__constant__ signed char HOM_TERMS[29][4] = {
+    {0, 0, -1, -1}, {0, 1, -1, -1}, {0, 2, -1, -1}, {1, 1, -1, -1}, {1, 2, -1, -1}, {2, 2, -1, -1},   // a_i a_j
+    {0, 3, -1, -1}, {0, 4, -1, -1}, {1, 3, -1, -1}, {1, 4, -1, -1}, {2, 3, -1, -1}, {2, 4, -1, -1},   // a_i b0_j
+    {-1, -1, 0, 5}, {-1, -1, 0, 6}, {-1, -1, 1, 5}, {-1, -1, 1, 6}, {-1, -1, 2, 5}, {-1, -1, 2, 6},   // a_i b1_j
+    {3, 3, 5, 5}, {3, 4, 5, 6}, {4, 4, 6, 6},                                                           // b_j b_k
+    {0, 7, -1, -1}, {1, 7, -1, -1}, {2, 7, -1, -1}, {-1, -1, 0, 8}, {-1, -1, 1, 8}, {-1, -1, 2, 8},   // J^T e 0..5
+    {3, 7, 5, 8}, {4, 7, 6, 8}};                                                                        // J^T e 6,7
+
+// index into the 29 sums of entry (r, c) of J^T J, -1 for the structural zeros
+__device__ __forceinline__ int hom_entry(int r, int c) {
+    if (r > c) { const int t = r; r = c; c = t; }
+    if (r < 3) {
+        if (c < 3) return r == 0 ? c : (r == 1 ? 2 + c : 5);
+        if (c < 6) return -1;
+        return 6 + r * 2 + (c - 6);
+    }
+    if (r < 6) {
+        if (c < 6) { const int i = r - 3, j = c - 3; return i == 0 ? j : (i == 1 ? 2 + j : 5); }
+        return 12 + (r - 3) * 2 + (c - 6);
+    }
+    return r == 6 ? 18 + (c - 6) : 20;
+}
+
+// errors() / jacobian() at h over the wave's points (homography.cpp:166-207); e = 0 - f because levmar forms
+// e = x - hx with x = NULL (lm_core.c:163-167)
+template <bool JAC>
+__device__ __forceinline__ void hom_eval(const float4 *P, int N, const double h[8], double *Q, double *E, int lane) {
+    for (int i = lane; i < N; i += 64) {
+        const float4 pt = P[i];
+        const float x1 = pt.x, y1 = pt.y, x2 = pt.z, y2 = pt.w;
+        double w = h[6] * x1 + h[7] * y1 + 1.0;
+        w = (w > DBL_EPSILON) ? 1.0 / w : 0.0;
+        const double xi = (h[0] * x1 + h[1] * y1 + h[2]) * w;
+        const double yi = (h[3] * x1 + h[4] * y1 + h[5]) * w;
+        const double e0 = 0.0 - (xi - x2), e1 = 0.0 - (yi - y2);
+        if (JAC) {
+            double *q = Q + (size_t)i * 9;
+            q[0] = x1 * w; q[1] = y1 * w; q[2] = w;
+            q[3] = -x1 * xi * w; q[4] = -y1 * xi * w;
+            q[5] = -x1 * yi * w; q[6] = -y1 * yi * w;
+            q[7] = e0; q[8] = e1;
+        } else {
+            E[2 * i] = e0; E[2 * i + 1] = e1;
+        }
+    }
+}
+
+// ||e||^2 in the order of LEVMAR_L2NRMXMY (misc_core.c:712-798): four interleaved chains over the blocks of 8
+// from the top down, then the tail; wave-uniform result
+__device__ __forceinline__ double hom_norm2(const double *E, int n, int lane) {
+    const int blockn = (n >> 3) << 3;
+    double s = 0.0;
+    if (lane < 4) {
+        for (int i = blockn - 1 - lane; i >= 0; i -= 4) { const double v = E[i]; s += v * v; }
+        for (int i = blockn; i < n; ++i)
+            if (((7 - (n - i)) & 3) == lane) { const double v = E[i]; s += v * v; }
+    }
+    return bcast(s, 0) + bcast(s, 1) + bcast(s, 2) + bcast(s, 3);
+}
+
+// (A + mu I) x = b for the 8x8 system held one entry per lane (lane = 8 r + c), b[r] replicated over row r.
+// Crout LU with implicitly scaled partial pivoting in the operation order of Axb_core.c:992-1139, forward
+// substitution folded into the elimination steps, back substitution on wave-uniform values.  Returns false
+// only for an all-zero row, as the reference does.
+__device__ __forceinline__ bool hom_lu_solve(double a, double bv, int lane, double x[8]) {
+    const int r = lane >> 3, c = lane & 7;
+    double big = fabs(a);
+    big = fmax(big, __shfl_xor(big, 1, 64));
+    big = fmax(big, __shfl_xor(big, 2, 64));
+    big = fmax(big, __shfl_xor(big, 4, 64));
+    if (__any(big == 0.0)) return false;
+    double sc = 1.0 / big;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double t = sc * fabs(a);
+        double best = 0.0;
+        int piv = -1;
+#pragma unroll
+        for (int rr = k; rr < 8; ++rr) {
+            const double tr = bcast(t, rr * 8 + k);
+            if (tr >= best) { best = tr; piv = rr; }
+        }
+        if (piv < 0) piv = k;
+        if (piv != k) {
+            const int srow = (r == k) ? piv : (r == piv ? k : r);
+            const int src = srow * 8 + c;
+            a = __shfl(a, src, 64);
+            bv = __shfl(bv, src, 64);
+            sc = __shfl(sc, src, 64);
+        }
+        double pv = bcast(a, k * 9);
+        if (pv == 0.0) {
+            pv = DBL_EPSILON;
+            if (lane == k * 9) a = pv;
+        }
+        if (k != 7) {
+            const double inv = 1.0 / pv;
+            if (c == k && r > k) a *= inv;
+            const double lrk = __shfl(a, (lane & 56) | k, 64);
+            const double ukc = __shfl(a, k * 8 + c, 64);
+            const double bk = bcast(bv, k * 8);
+            if (r > k) {
+                if (c > k) a -= lrk * ukc;
+                bv -= lrk * bk;
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 7; rr >= 0; --rr) {
+        double acc = bcast(bv, rr * 8);
+#pragma unroll
+        for (int kk = rr + 1; kk < 8; ++kk) acc -= bcast(a, rr * 8 + kk) * x[kk];
+        x[rr] = acc / bcast(a, rr * 9);
+    }
+    return true;
+}
+
+// one block = one wave = one problem; dynamic LDS = hom_lds_doubles(max points of any problem) * 8 bytes
+__global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
+    extern __shared__ double4 hom_lds_raw[];
+    double *lds = reinterpret_cast<double *>(hom_lds_raw);
+    const int prob = blockIdx.x, lane = threadIdx.x;
+    const int o0 = a.off[prob], N = a.off[prob + 1] - o0, n = 2 * N;
+    double *Hp = a.H + (size_t)prob * 9;
+    if (n < 8) {      // lm_core.c:117-120: fewer measurements than unknowns -> LM_ERROR, parameters untouched
+        if (lane == 0 && a.ret) a.ret[prob] = -1;
+        if (lane < 10 && a.info) a.info[(size_t)prob * 10 + lane] = 0.0;
+        return;
+    }
+    float4 *P = reinterpret_cast<float4 *>(lds);
+    double *Q = lds + 2 * (size_t)N, *E = Q + 9 * (size_t)N, *S = E + 2 * (size_t)N;
+    for (int i = lane; i < N; i += 64) P[i] = make_float4(a.x1[o0 + i], a.y1[o0 + i], a.x2[o0 + i], a.y2[o0 + i]);
+
+    const int r = lane >> 3, c = lane & 7;
+    const int entry = hom_entry(r, c);
+    int c0 = -1, d0 = -1, c1 = -1, d1 = -1;
+    if (lane < 29) { c0 = HOM_TERMS[lane][0]; d0 = HOM_TERMS[lane][1]; c1 = HOM_TERMS[lane][2]; d1 = HOM_TERMS[lane][3]; }
+    const bool is_jte = lane >= 21;
+    const bool small = (long)n * 8 < 32 * 32;          // lm_core.c:206 (nm < __BLOCKSZ__SQ)
+
+    double p[8], pDp[8], Dp[8], jte[8], diag[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { p[i] = Hp[i]; diag[i] = 0.0; jte[i] = 0.0; Dp[i] = 0.0; pDp[i] = 0.0; }
+    const double eps2_sq = a.eps2 * a.eps2;
+    double mu = 0.0, jacTe_inf = 0.0, p_L2 = 0.0, Dp_L2 = DBL_MAX, p_eL2, pDp_eL2, ajj = 0.0;
+    int nu = 2, stop = 0, nfev = 1, njev = 0, nlss = 0, k;
+
+    __syncthreads();
+    hom_eval<false>(P, N, p, Q, E, lane);
+    __syncthreads();
+    p_eL2 = hom_norm2(E, n, lane);
+    const double init_p_eL2 = p_eL2;
+    if (!isfinite(p_eL2)) stop = 7;
+
+    for (k = 0; k < a.itmax && !stop; ++k) {
+        if (p_eL2 <= a.eps3) { stop = 6; break; }
+        __syncthreads();
+        hom_eval<true>(P, N, p, Q, E, lane);
+        ++njev;
+        __syncthreads();
+        if (lane < 29) {
+            double res;
+            if (small) {            // lm_core.c:217-237: rows from the last to the first, one running sum
+                double s = 0.0;
+                for (int pt = N - 1; pt >= 0; --pt) {
+                    const double *q = Q + (size_t)pt * 9;
+                    if (c1 >= 0) s += q[c1] * q[d1];
+                    if (c0 >= 0) s += q[c0] * q[d0];
+                }
+                res = s;
+            } else {                // misc_core.c:80-132: 32-row partial sums; J^T e row by row (lm_core.c:246-254)
+                double tot = 0.0, part = 0.0;
+                for (int b0 = 0; b0 < N; b0 += 16) {
+                    const int be = b0 + 16 < N ? b0 + 16 : N;
+                    if (!is_jte) part = 0.0;
+                    for (int pt = b0; pt < be; ++pt) {
+                        const double *q = Q + (size_t)pt * 9;
+                        if (c0 >= 0) part += q[c0] * q[d0];
+                        if (c1 >= 0) part += q[c1] * q[d1];
+                    }
+                    if (!is_jte) tot += part;
+                }
+                res = is_jte ? part : tot;
+            }
+            S[lane] = res;
+        }
+        __syncthreads();
+        ajj = entry >= 0 ? S[entry] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { jte[i] = S[21 + i]; diag[i] = S[hom_entry(i, i)]; }
+        p_L2 = 0.0; jacTe_inf = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double t = fabs(jte[i]);
+            if (jacTe_inf < t) jacTe_inf = t;
+            p_L2 += p[i] * p[i];
+        }
+        if (jacTe_inf <= a.eps1) { Dp_L2 = 0.0; stop = 1; break; }
+        if (k == 0) {
+            double t = -DBL_MAX;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (diag[i] > t) t = diag[i];
+            mu = a.tau * t;
+        }
+        const double brow = S[21 + r];
+        for (;;) {
+            const double aug = (r == c) ? ajj + mu : ajj;
+            const bool ok = hom_lu_solve(aug, brow, lane, Dp);
+            ++nlss;
+            if (ok) {
+                Dp_L2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { pDp[i] = p[i] + Dp[i]; Dp_L2 += Dp[i] * Dp[i]; }
+                if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
+                if (Dp_L2 >= (p_L2 + a.eps2) / (1e-12 * 1e-12)) { stop = 4; break; }
+                __syncthreads();
+                hom_eval<false>(P, N, pDp, Q, E, lane);
+                ++nfev;
+                __syncthreads();
+                pDp_eL2 = hom_norm2(E, n, lane);
+                if (!isfinite(pDp_eL2)) { stop = 7; break; }
+                double dL = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dL += Dp[i] * (mu * Dp[i] + jte[i]);
+                const double dF = p_eL2 - pDp_eL2;
+                if (dL > 0.0 && dF > 0.0) {
+                    double t = 2.0 * dF / dL - 1.0;
+                    t = 1.0 - t * t * t;
+                    mu = mu * ((t >= 0.3333333334) ? t : 0.3333333334);
+                    nu = 2;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) p[i] = pDp[i];
+                    p_eL2 = pDp_eL2;
+                    break;
+                }
+            }
+            mu *= nu;
+            const int nu2 = (int)((unsigned)nu << 1);
+            if (nu2 <= nu) { stop = 5; break; }
+            nu = nu2;
+        }
+    }
+    if (k >= a.itmax && !stop) stop = 3;
+
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Hp[i] = p[i];
+        Hp[8] = 1.0;                                   // homography.cpp:233
+        if (a.ret) a.ret[prob] = (stop != 4 && stop != 7) ? k : -1;
+        if (a.info) {
+            double mx = DBL_MIN;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (diag[i] > mx) mx = diag[i];
+            double *o = a.info + (size_t)prob * 10;
+            o[0] = init_p_eL2; o[1] = p_eL2; o[2] = jacTe_inf; o[3] = Dp_L2; o[4] = mu / mx;
+            o[5] = (double)k; o[6] = (double)stop; o[7] = (double)nfev; o[8] = (double)njev; o[9] = (double)nlss;
+        }
+    }
+}
+
+}  // namespace cvxhom

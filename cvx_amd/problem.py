@@ -234,3 +234,50 @@ def shard_calib(data, first, rank):
         out[k] = data[k][v0:v1].copy()
     out.update(V=v1 - v0, N=o1 - o0)
     return out
+
+
+class HomographyBatch:
+    """cvx_homography handle: HomographyEstimator::solveLM (homography.cpp:218-236) for many views at once.
+    Point pairs are float32 (cv::Point2f), problem i owning [off[i], off[i+1])."""
+
+    def __init__(self, off, x1, y1, x2, y2, device=0, stream=None):
+        self.off = i32(off)
+        self.pts = [np.ascontiguousarray(a, dtype=np.float32) for a in (x1, y1, x2, y2)]
+        self.n = len(self.off) - 1
+        fp = lambda a: a.ctypes.data_as(capi.fp)
+        self.h = C.c_void_p()
+        check(lib().cvx_homography_create(self.n, pi(self.off), *[fp(a) for a in self.pts], int(device),
+                                          C.c_void_p(stream) if stream else None, C.byref(self.h)),
+              "cvx_homography_create")
+
+    def close(self):
+        if self.h:
+            lib().cvx_homography_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, H, max_iter=100, opts=None):
+        """H [n, 9] initial estimates -> (H refined, info [n, 10], ret [n])"""
+        H = f64(np.array(H, dtype=np.float64).reshape(self.n, 9))
+        info = np.zeros((self.n, 10)); ret = np.zeros(self.n, np.int32)
+        o = f64(opts) if opts is not None else None
+        check(lib().cvx_homography_solve(self.h, pd(H), int(max_iter), pd(o) if o is not None else None, pd(info),
+                                         pi(ret)), "cvx_homography_solve")
+        return H, info, ret
+
+    def set(self, H):
+        H = f64(np.array(H, dtype=np.float64).reshape(self.n, 9))
+        check(lib().cvx_homography_set(self.h, pd(H)), "cvx_homography_set")
+
+    def run(self, max_iter=100):
+        check(lib().cvx_homography_run(self.h, int(max_iter), None), "cvx_homography_run")
+
+    def get(self):
+        H = np.zeros((self.n, 9)); info = np.zeros((self.n, 10)); ret = np.zeros(self.n, np.int32)
+        check(lib().cvx_homography_get(self.h, pd(H), pd(info), pi(ret)), "cvx_homography_get")
+        return H, info, ret

@@ -243,6 +243,31 @@ int cvx_handeye_pairs_moving(int n, const double *gripper_to_base, const double 
 int cvx_handeye_linear(int method, int n, const double *A, const double *B, double X[16]);
 
 /* ------------------------------------------------------------------------ */
+/* Batched homography refinement                        */
+/* ------------------------------------------------------------------------ */
+/* HomographyEstimator::solveLM (homography.cpp:218-236) for n_problems independent views in one launch:
+ * functor LMHomographyEstimator (homography.cpp:166-207: 2 residuals and the analytic 2x8 Jacobian rows per
+ * point pair), engine levmar's dlevmar_der (lm_core.c:60-423, LU solve Axb_core.c:992-1139) with the options
+ * LMSolver::minimizeDer builds (lm.hpp:61).  One problem per 64-lane wave; all sums in the reference's order,
+ * so each problem's result is bit-identical to the CPU reference's.
+ * Point pairs are cv::Point2f, already gathered by the inlier list (homography.cpp:170), problem i owning
+ * [off[i], off[i+1]); a problem with fewer than 4 pairs is left untouched and reports ret = -1
+ * (lm_core.c:117-120). */
+#define CVX_HOMOGRAPHY_MAX_POINTS 1024
+typedef struct cvx_homography cvx_homography;
+int cvx_homography_create(int n_problems, const int *off, const float *x1, const float *y1, const float *x2,
+                          const float *y2, int device, void *stream, cvx_homography **out);
+void cvx_homography_destroy(cvx_homography *h);
+/* H: n_problems x 9 row-major, in: initial estimates with H(2,2) = 1 assumed (homography.cpp:229), out:
+ * {h0..h7, 1} (:233).  opts: NULL = {1e-3, eps, eps, eps} (lm.hpp:43-46,61) else levmar's opts[0..3].
+ * info: n_problems x 10 levmar info[] (or NULL); ret: dlevmar_der's return value per problem (or NULL). */
+int cvx_homography_solve(cvx_homography *h, double *H, int max_iter, const double *opts, double *info, int *ret);
+/* the same in three steps, so that a caller can keep the estimates resident and time the launch alone */
+int cvx_homography_set(cvx_homography *h, const double *H);
+int cvx_homography_run(cvx_homography *h, int max_iter, const double *opts);
+int cvx_homography_get(cvx_homography *h, double *H, double *info, int *ret);
+
+/* ------------------------------------------------------------------------ */
 /* On-disk formats either side of the path (host only)   */
 /* ------------------------------------------------------------------------ */
 /* CameraCalibration::Data::load (calibration.cpp:49-79): "w h", n_coords + "x y z" lines, n_views, then per

@@ -1197,3 +1197,57 @@ int orc_lm_nielsen_der(orc_lm_func func, orc_lm_func jacf, double *p, const doub
     free(e); free(hx); free(jac); free(JtJ); free(A); free(Jte); free(Dp); free(pDp);
     return (stop != 4 && stop != 7) ? k : -1;
 }
+
+/* ======================================================================== */
+/* homography LM: homography.cpp:159-236 on top of the levmar engine          */
+/* ======================================================================== */
+typedef struct { int n; const float *x1, *y1, *x2, *y2; } hom_ctx;
+
+void orc_homography_errors(int n, const float *px1, const float *py1, const float *px2, const float *py2,
+                           const double h[8], double *e) {
+    for (int i = 0; i < n; ++i) {
+        const float x1 = px1[i], y1 = py1[i], x2 = px2[i], y2 = py2[i];
+        double w = h[6] * x1 + h[7] * y1 + 1.0;
+        w = (w > DBL_EPSILON) ? 1.0 / w : 0.0;
+        const double xi = (h[0] * x1 + h[1] * y1 + h[2]) * w;
+        const double yi = (h[3] * x1 + h[4] * y1 + h[5]) * w;
+        e[2 * i] = xi - x2;
+        e[2 * i + 1] = yi - y2;
+    }
+}
+
+void orc_homography_jacobian(int n, const float *px1, const float *py1, const double h[8], double *J) {
+    for (int i = 0; i < n; ++i) {
+        const float x1 = px1[i], y1 = py1[i];
+        double w = h[6] * x1 + h[7] * y1 + 1.0;
+        w = (w > DBL_EPSILON) ? 1.0 / w : 0.0;
+        const double xi = (h[0] * x1 + h[1] * y1 + h[2]) * w;
+        const double yi = (h[3] * x1 + h[4] * y1 + h[5]) * w;
+        double *r0 = J + (size_t)(2 * i) * 8, *r1 = r0 + 8;
+        r0[0] = x1 * w; r0[1] = y1 * w; r0[2] = w; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -x1 * xi * w; r0[7] = -y1 * xi * w;
+        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x1 * w; r1[4] = y1 * w; r1[5] = w; r1[6] = -x1 * yi * w; r1[7] = -y1 * yi * w;
+    }
+}
+
+static void hom_func(double *p, double *hx, int m, int n, void *adata) {
+    const hom_ctx *c = adata; (void)m; (void)n;
+    orc_homography_errors(c->n, c->x1, c->y1, c->x2, c->y2, p, hx);
+}
+static void hom_jac(double *p, double *j, int m, int n, void *adata) {
+    const hom_ctx *c = adata; (void)m; (void)n;
+    orc_homography_jacobian(c->n, c->x1, c->y1, p, j);
+}
+
+typedef int (*dlevmar_der_fn)(orc_lm_func, orc_lm_func, double *, double *, int, int, int, double *, double *,
+                              double *, double *, void *);
+
+int orc_homography_lm(void *engine, int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                      double h[8], int itmax, const double opts[4], double info[10]) {
+    hom_ctx c = { n, x1, y1, x2, y2 };
+    if (2 * n < 8) return -1;
+    if (engine) {
+        double o[5] = { opts[0], opts[1], opts[2], opts[3], 0.0 };
+        return ((dlevmar_der_fn)engine)(hom_func, hom_jac, h, NULL, 8, 2 * n, itmax, o, info, NULL, NULL, &c);
+    }
+    return orc_lm_nielsen_der(hom_func, hom_jac, h, NULL, 8, 2 * n, itmax, opts, info, &c);
+}

@@ -162,6 +162,18 @@ int orc_lm_nielsen_der(orc_lm_func func, orc_lm_func jacf, double *p, const doub
                        int m, int n, int itmax, const double opts[4], double info[10],
                        void *adata);
 
+/* ---- HomographyEstimator::solveLM, homography.cpp:159-236 ------------------ */
+/* errors (homography.cpp:166-186) and jacobian (:188-207) of LMHomographyEstimator over n point pairs
+ * (already gathered by the inlier list); h[8] in/out; opts as LMSolver::minimizeDer builds them
+ * (lm.hpp:61: {factor, g_tol, x_tol, g_tol}); x = NULL.  engine: NULL = this file's restatement
+ * (orc_lm_nielsen_der), else the address of the reference's dlevmar_der (oracle/_ref).  Returns what
+ * dlevmar_der returns; -1 and h untouched when 2n < 8 (lm_core.c:117-120). */
+int orc_homography_lm(void *engine, int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                      double h[8], int itmax, const double opts[4], double info[10]);
+void orc_homography_errors(int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                           const double h[8], double *e /* 2n */);
+void orc_homography_jacobian(int n, const float *x1, const float *y1, const double h[8], double *J /* 2n x 8 */);
+
 /* LU solve of the no-LAPACK levmar build (Axb_core.c:992-1139); A, b preserved */
 int orc_lu_solve(int n, const double *A, const double *b, double *x);
 /* dense SPD solve used by the drivers (Cholesky); returns 0 on failure */

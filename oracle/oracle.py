@@ -101,6 +101,11 @@ def lib():
         L.orc_lm_nielsen_der.argtypes = [LM_FUNC, LM_FUNC, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_void_p]
         L.orc_lm_nielsen_der.restype = C.c_int
         L.orc_cholesky_solve.argtypes = [C.c_int, dp, dp]; L.orc_cholesky_solve.restype = C.c_int
+        fp = C.POINTER(C.c_float)
+        L.orc_homography_lm.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, dp, C.c_int, dp, dp]
+        L.orc_homography_lm.restype = C.c_int
+        L.orc_homography_errors.argtypes = [C.c_int, fp, fp, fp, fp, dp, dp]
+        L.orc_homography_jacobian.argtypes = [C.c_int, fp, fp, dp, dp]
         _LIB = L
     return _LIB
 
@@ -233,3 +238,27 @@ def handeye(q, t, qa, ta, qb, tb, autodiff=False):
     f = lib().orc_handeye_autodiff if autodiff else lib().orc_handeye_analytic
     f(*[_dp(v) for v in a], _dp(r), _dp(Jq), _dp(Jt))
     return r, Jq, Jt
+
+
+LEVMAR_OPTS = (1e-3, np.finfo(np.float64).eps, np.finfo(np.float64).eps, np.finfo(np.float64).eps)   # lm.hpp:43-46,61
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def homography_lm(x1, y1, x2, y2, h, itmax=100, opts=LEVMAR_OPTS, engine="restatement"):
+    """HomographyEstimator::solveLM (homography.cpp:218-236) on one problem: h[8] -> (ret, h, info[10]).
+    engine "restatement" = this repo's levmar restatement, "reference" = the reference's dlevmar_der compiled
+    into oracle/_ref (None is returned when that library is absent, as on the GPU box if it did not travel)."""
+    x1, y1, x2, y2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (x1, y1, x2, y2))
+    hh = np.array(h, dtype=np.float64).reshape(-1)[:8].copy()
+    o = np.array(opts, dtype=np.float64); info = np.zeros(10)
+    fn = None
+    if engine == "reference":
+        R = levmar_ref()
+        if R is None:
+            return None
+        fn = C.cast(R.dlevmar_der, C.c_void_p)
+    ret = lib().orc_homography_lm(fn, len(x1), _fp(x1), _fp(y1), _fp(x2), _fp(y2), _dp(hh), int(itmax), _dp(o), _dp(info))
+    return ret, hh, info

@@ -150,3 +150,18 @@ def test_partition_views_balances_observations():
 def test_refine_return_value():
     # sqrt(total_cost / (2 N)), calibration.cpp:463
     assert capi.lib().cvx_calib_refine_return(8.0, 4) == 1.0
+
+
+def test_homography_batch_argument_checks():
+    """host-side validation happens before any device work (include/cvx_amd.h, CVX_HOMOGRAPHY_MAX_POINTS)"""
+    from cvx_amd.problem import HomographyBatch
+    z = np.zeros(1025, np.float32)
+    with pytest.raises(capi.CvxError) as e:
+        HomographyBatch([0, 1025], z, z, z, z)
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.CvxError) as e:
+        HomographyBatch([1, 5], z, z, z, z)
+    assert e.value.status == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.CvxError) as e:
+        HomographyBatch([0, 5, 3], z, z, z, z)
+    assert e.value.status == capi.ERR_INVALID_ARG

@@ -1,0 +1,107 @@
+"""GPU: the batched homography LM kernel (cvx_amd/csrc/homography_kernels.h) through the C ABI against the
+oracle.  Bar: BIT-exact -- the kernel evaluates every sum in the reference's order, so parameters, levmar's
+info[] and the return value must equal the CPU reference's exactly (tests/golden/homography_lm.json holds runs
+of the reference's own levmar; oracle/cvx_oracle.c is pinned to it by tests/test_homography_oracle.py)."""
+import numpy as np
+import pytest
+
+import cvx_amd
+from cvx_amd import capi
+from cvx_amd.problem import HomographyBatch
+from conftest import load_golden
+from test_helpers import homography_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_batch(orc, off, x1, y1, x2, y2, H0, itmax=100, which=None):
+    out = {}
+    for i in (range(len(off) - 1) if which is None else which):
+        s = slice(off[i], off[i + 1])
+        if off[i + 1] - off[i] < 4:
+            out[i] = (-1, np.array(H0[i][:8]), np.zeros(10))
+        else:
+            out[i] = orc.homography_lm(x1[s], y1[s], x2[s], y2[s], H0[i], itmax=itmax)
+    return out
+
+
+def test_golden_reference_levmar_runs_bit_exact():
+    gold = load_golden("homography_lm.json")
+    names = sorted(gold)
+    for itmax in sorted({gold[n]["itmax"] for n in names}):
+        sel = [n for n in names if gold[n]["itmax"] == itmax]
+        off = np.concatenate([[0], np.cumsum([len(gold[n]["x1"]) for n in sel])]).astype(np.int32)
+        cat = lambda k: np.concatenate([np.array(gold[n][k], dtype=np.float32) for n in sel])
+        b = HomographyBatch(off, cat("x1"), cat("y1"), cat("x2"), cat("y2"))
+        H, info, ret = b.solve(np.stack([gold[n]["H0"] for n in sel]), max_iter=itmax)
+        for i, n in enumerate(sel):
+            g = gold[n]
+            assert ret[i] == g["ret"], n
+            if g["ret"] >= 0:
+                assert H[i, :8].tolist() == g["h"], n
+                assert H[i, 8] == 1.0
+                assert info[i].tolist() == g["info"], n
+            else:                                   # fewer than 4 pairs: untouched (lm_core.c:117-120)
+                assert H[i].tolist() == g["H0"], n
+
+
+def test_random_ragged_batch_bit_exact_against_oracle(orc):
+    rng = np.random.default_rng(2026)
+    sizes = np.concatenate([rng.integers(4, 200, 250), [4, 5, 63, 64, 65, 108, 512, 3, 0, 1]])
+    off, x1, y1, x2, y2, H0 = homography_batch(rng, np.maximum(sizes, 1))
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    H, info, ret = b.solve(H0)
+    ref = _oracle_batch(orc, off, x1, y1, x2, y2, H0)
+    for i, (r, h, inf) in ref.items():
+        assert ret[i] == r, i
+        if r >= 0:
+            assert H[i, :8].tolist() == h.tolist(), i
+            assert info[i].tolist() == inf.tolist(), i
+        else:
+            assert H[i].tolist() == H0[i].tolist(), i
+
+
+def test_empty_and_tiny_problems_inside_a_batch(orc):
+    rng = np.random.default_rng(5)
+    off, x1, y1, x2, y2, H0 = homography_batch(rng, [20, 3, 30])
+    off = np.array([0, 20, 20, 23, 53, 53], dtype=np.int32)            # 20, 0, 3, 30, 0 pairs
+    H0 = np.stack([H0[0], H0[1], H0[1], H0[2], H0[2]])
+    H, info, ret = HomographyBatch(off, x1, y1, x2, y2).solve(H0)
+    assert ret[1] == -1 and ret[2] == -1 and ret[4] == -1
+    for i in (1, 2, 4):
+        assert H[i].tolist() == H0[i].tolist()
+    ref = _oracle_batch(orc, off, x1, y1, x2, y2, H0, which=[0, 3])
+    for i, (r, h, inf) in ref.items():
+        assert ret[i] == r and H[i, :8].tolist() == h.tolist() and info[i].tolist() == inf.tolist()
+
+
+def test_full_size_batch_properties_and_sampled_parity(orc):
+    """BASELINE config 4's view count: 10 000 views x 108 board points.  Properties that hold at any size
+    (cost never increases, a restart from the result gains nothing) plus bit-exact parity on a sample."""
+    rng = np.random.default_rng(4)
+    n = 10000
+    base = homography_batch(rng, [108] * 50)
+    rep = n // 50
+    off = (np.arange(n + 1) * 108).astype(np.int32)
+    x1, y1, x2, y2 = (np.tile(a, rep) for a in base[1:5])
+    H0 = np.tile(base[5], (rep, 1)) * (1 + 1e-3 * rng.normal(size=(n, 1)))       # distinct starts per view
+    H0 /= H0[:, 8:9]
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    H, info, ret = b.solve(H0)
+    assert np.all(ret > 0) and np.all(info[:, 1] <= info[:, 0]) and np.all(np.isin(info[:, 6], (1, 2, 3, 6)))
+    H2, info2, _ = b.solve(H)
+    assert np.all(np.abs(info2[:, 1] - info[:, 1]) <= 1e-9 * info[:, 1])
+    ref = _oracle_batch(orc, off, x1, y1, x2, y2, H0, which=range(0, n, 397))
+    for i, (r, h, inf) in ref.items():
+        assert ret[i] == r and H[i, :8].tolist() == h.tolist() and info[i].tolist() == inf.tolist()
+
+
+def test_custom_options_and_iteration_cap(orc):
+    rng = np.random.default_rng(8)
+    off, x1, y1, x2, y2, H0 = homography_batch(rng, [54, 108, 70])
+    opts = (1e-2, 1e-9, 1e-9, 1e-3)
+    H, info, ret = HomographyBatch(off, x1, y1, x2, y2).solve(H0, max_iter=7, opts=opts)
+    for i in range(3):
+        s = slice(off[i], off[i + 1])
+        r, h, inf = orc.homography_lm(x1[s], y1[s], x2[s], y2[s], H0[i], itmax=7, opts=opts)
+        assert ret[i] == r and H[i, :8].tolist() == h.tolist() and info[i].tolist() == inf.tolist()

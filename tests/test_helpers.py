@@ -37,3 +37,27 @@ def calib_from_fixture(g):
             "view_off": view_off, "point_id": point_id, "obs_x": ox, "obs_y": oy,
             "intr": np.array(g["cameras"]), "poses": np.array(g["poses"]), "points": np.array(g["points"]),
             "r": r, "Jc": J[:, :, :9], "Jp": J[:, :, 9:15], "Jx": J[:, :, 15:]}
+
+
+def homography_problem(rng, N, noise=0.3, perturb=1e-2):
+    """N board points (12 x 9 grid of 25 mm tiles, pattern.hpp:53-55) seen through a random homography with
+    pixel noise, float32 like cv::Point2f, and a perturbed initial estimate normalised to H(2,2) = 1."""
+    bx, by = np.meshgrid(np.arange(12) * 25.0, np.arange(9) * 25.0)
+    idx = rng.permutation(108)[:N] if N <= 108 else rng.integers(0, 108, N)
+    x1 = bx.ravel()[idx].astype(np.float32); y1 = by.ravel()[idx].astype(np.float32)
+    H = np.array([[3.5, 0.3, 400.0], [-0.2, 3.6, 300.0], [2e-4, -3e-4, 1.0]])
+    H = H + rng.normal(0, 1, (3, 3)) * np.array([[0.1, 0.1, 20], [0.1, 0.1, 20], [1e-4, 1e-4, 0]])
+    q = H @ np.stack([x1.astype(np.float64), y1.astype(np.float64), np.ones(N)])
+    x2 = (q[0] / q[2] + rng.normal(0, noise, N)).astype(np.float32)
+    y2 = (q[1] / q[2] + rng.normal(0, noise, N)).astype(np.float32)
+    H0 = H * (1 + rng.normal(0, perturb, (3, 3)))
+    H0 /= H0[2, 2]
+    return x1, y1, x2, y2, H0.reshape(-1)
+
+
+def homography_batch(rng, sizes, **kw):
+    """concatenated problems -> off, x1, y1, x2, y2, H0[n, 9]"""
+    parts = [homography_problem(rng, int(n), **kw) for n in sizes]
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.int32)
+    cat = lambda k: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, np.float32)
+    return off, cat(0), cat(1), cat(2), cat(3), np.stack([p[4] for p in parts])
