@@ -84,6 +84,53 @@ def cpu_baseline(views_per_camera, iters):
             "lm_iterations_per_s_at_full_size": (d["N"] * s.iterations / dt) / (CAMERAS * VIEWS_PER_CAMERA * BOARD_W * BOARD_H)}
 
 
+def homography_bench(cvx_amd, torch, device, with_cpu, n=CAMERAS * VIEWS_PER_CAMERA, P=BOARD_W * BOARD_H):
+    """HomographyEstimator::solveLM for every view of config 4 in one launch (board -> image point pairs with
+    0.3 px noise, starts 1 % off), beside the reference's levmar on a sample of the same problems."""
+    from cvx_amd.problem import HomographyBatch
+    rng = np.random.default_rng(SEED)
+    bx, by = np.meshgrid(np.arange(BOARD_W) * 25.0, np.arange(BOARD_H) * 25.0)
+    x1 = np.tile(bx.ravel(), n).astype(np.float32); y1 = np.tile(by.ravel(), n).astype(np.float32)
+    H = np.array([3.5, 0.3, 400.0, -0.2, 3.6, 300.0, 2e-4, -3e-4, 1.0]) + rng.normal(size=(n, 9)) * np.array(
+        [0.1, 0.1, 20, 0.1, 0.1, 20, 1e-4, 1e-4, 0])
+    Hr = np.repeat(H, P, axis=0)
+    w = Hr[:, 6] * x1 + Hr[:, 7] * y1 + 1.0
+    x2 = ((Hr[:, 0] * x1 + Hr[:, 1] * y1 + Hr[:, 2]) / w + rng.normal(0, 0.3, n * P)).astype(np.float32)
+    y2 = ((Hr[:, 3] * x1 + Hr[:, 4] * y1 + Hr[:, 5]) / w + rng.normal(0, 0.3, n * P)).astype(np.float32)
+    H0 = H * (1 + rng.normal(0, 1e-2, (n, 9)))
+    H0 /= H0[:, 8:9]
+    off = (np.arange(n + 1) * P).astype(np.int32)
+    b = HomographyBatch(off, x1, y1, x2, y2, device=device)
+    b.set(H0); b.run()
+    reps = 5
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        b.set(H0)
+        b.run()
+    dt = (time.perf_counter() - t) / reps
+    Hf, info, ret = b.get()
+    b.close()
+    out = {"problems": n, "point_pairs_per_problem": P, "ms_per_batch": 1e3 * dt, "problems_per_s": n / dt,
+           "lm_iterations_total": int(info[:, 5].sum()), "residual_evaluations_total": int(info[:, 7].sum()),
+           "converged": int(np.sum(ret > 0)), "kernel": "k_homography_lm (includes the 0.7 MB upload of the starts)"}
+    if with_cpu:
+        from oracle import oracle as orc
+        kind = "reference" if orc.levmar_ref() is not None else "port"
+        m = 400
+        t = time.perf_counter()
+        same = 0
+        for i in range(m):
+            s = slice(off[i], off[i + 1])
+            r, h, inf = orc.homography_lm(x1[s], y1[s], x2[s], y2[s], H0[i], engine="reference" if kind == "reference" else "restatement")
+            same += int(h.tolist() == Hf[i, :8].tolist())
+        dtc = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": m / dtc, "unit": "problems/s", "cores": 1, "kind": kind,
+                               "sample": "first %d of the %d problems through levmar dlevmar_der, %.2f s" % (m, n, dtc),
+                               "bit_identical_to_gpu": "%d of %d" % (same, m)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +252,11 @@ def main():
                              "iterations_per_solve": hs.iterations, "final_cost": hs.final_cost}
             he.close()
 
+    # ---- batched homography refinement, one LM problem per view of config 4 ----
+    homography = None
+    if rank == 0:
+        homography = homography_bench(cvx_amd, torch, local_rank, with_cpu=(world == 1 and not a.no_cpu_baseline))
+
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -268,6 +320,7 @@ def main():
                                   "frac": EVAL_BYTES_PER_OBS * N / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         out["handeye"] = handeye
+        out["homography"] = homography
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_views, a.cpu_iters)
         print(json.dumps(out), flush=True)

@@ -96,11 +96,25 @@ extern "C" int cvx_homography_run(cvx_homography *h, int max_iter, const double 
     a.eps1 = opts ? opts[1] : DBL_EPSILON;
     a.eps2 = opts ? opts[2] : DBL_EPSILON;
     a.eps3 = opts ? opts[3] : DBL_EPSILON;
+    a.prof = nullptr;
+#ifdef HOM_PROF
+    CVX_HIP(hipMalloc(&a.prof, sizeof(long long) * 5 * h->n));
+#endif
     CVX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_homography_lm),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     hipLaunchKernelGGL(k_homography_lm, dim3(h->n), dim3(64), h->lds_bytes, h->stream, a);
     CVX_HIP(hipGetLastError());
     CVX_HIP(hipStreamSynchronize(h->stream));
+#ifdef HOM_PROF
+    {
+        std::vector<long long> pr((size_t)5 * h->n);
+        CVX_HIP(hipMemcpy(pr.data(), a.prof, sizeof(long long) * pr.size(), hipMemcpyDeviceToHost));
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < h->n; ++i) for (int k = 0; k < 5; ++k) s[k] += (double)pr[(size_t)i * 5 + k];
+        std::fprintf(stderr, "HOM_PROF mean cycles per problem: eval %.0f sums %.0f norm %.0f lu %.0f total %.0f\n", s[0] / h->n, s[1] / h->n, s[2] / h->n, s[3] / h->n, s[4] / h->n);
+        (void)hipFree(a.prof);
+    }
+#endif
     return CVX_OK;
 }
 

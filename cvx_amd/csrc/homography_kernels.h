@@ -24,10 +24,17 @@ struct HomArgs {
     int *ret;                               // [n_problems] dlevmar_der return value (may be null)
     int n_problems, itmax;
     double tau, eps1, eps2, eps3;           // opts[0..3] as lm.hpp:61 builds them
+    long long *prof;                        // -DHOM_PROF builds only: [n_problems][4] cycles in eval, sums, norm, LU
 };
 
+#ifdef HOM_PROF
+#define HOM_T(slot, stmt) { const long long t__ = clock64(); stmt; prof_acc[slot] += clock64() - t__; }
+#else
+#define HOM_T(slot, stmt) { stmt; }
+#endif
+
 constexpr int HOM_SCRATCH = 32;                                   // doubles of per-wave exchange space
-__host__ __device__ inline size_t hom_lds_doubles(int n_points) { return (size_t)13 * n_points + HOM_SCRATCH; }
+__host__ __device__ inline size_t hom_lds_doubles(int n_points) { return (size_t)14 * n_points + HOM_SCRATCH; }
 
 __device__ __forceinline__ double bcast(double v, int lane /* wave-uniform */) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -38,8 +45,9 @@ __device__ __forceinline__ double bcast(double v, int lane /* wave-uniform */) {
 
 // Which products lane L sums.  Per point the Jacobian rows are (homography.cpp:204-205)
 //   even row: a0 a1 a2 0 0 0 b00 b01      odd row: 0 0 0 a0 a1 a2 b10 b11
-// stored as Q[pt] = {a0, a1, a2, b00, b01, b10, b11, e_even, e_odd}.  {c0, d0} = columns of Q multiplied for the
-// even row's term, {c1, d1} for the odd row's, -1 = structurally zero.  Lanes 0-20: the distinct entries of
+// stored as Q[pt] = {a0, a1, a2, b00, b01, b10, b11, e_even, e_odd, 0}.  {c0, d0} = columns of Q multiplied for the
+// even row's term, {c1, d1} for the odd row's, -1 = structurally zero (read from the zero column: the
+// reference adds those +0 products too, lm_core.c:228 / misc_core.c:113, so the sums stay bit-identical).  Lanes 0-20: the distinct entries of
 // J^T J; lanes 21-28: J^T e.
 __constant__ signed char HOM_TERMS[29][4] = {
     {0, 0, -1, -1}, {0, 1, -1, -1}, {0, 2, -1, -1}, {1, 1, -1, -1}, {1, 2, -1, -1}, {2, 2, -1, -1},   // a_i a_j
@@ -77,11 +85,11 @@ __device__ __forceinline__ void hom_eval(const float4 *P, int N, const double h[
         const double yi = (h[3] * x1 + h[4] * y1 + h[5]) * w;
         const double e0 = 0.0 - (xi - x2), e1 = 0.0 - (yi - y2);
         if (JAC) {
-            double *q = Q + (size_t)i * 9;
+            double *q = Q + (size_t)i * 10;
             q[0] = x1 * w; q[1] = y1 * w; q[2] = w;
             q[3] = -x1 * xi * w; q[4] = -y1 * xi * w;
             q[5] = -x1 * yi * w; q[6] = -y1 * yi * w;
-            q[7] = e0; q[8] = e1;
+            q[7] = e0; q[8] = e1; q[9] = 0.0;
         } else {
             E[2 * i] = e0; E[2 * i + 1] = e1;
         }
@@ -94,8 +102,17 @@ __device__ __forceinline__ double hom_norm2(const double *E, int n, int lane) {
     const int blockn = (n >> 3) << 3;
     double s = 0.0;
     if (lane < 4) {
-        for (int i = blockn - 1 - lane; i >= 0; i -= 4) { const double v = E[i]; s += v * v; }
-        for (int i = blockn; i < n; ++i)
+        int i = blockn - 1 - lane;
+        // eight loads in flight per step of the chain (the adds stay in order)
+        for (; i >= 28; i -= 32) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = E[i - 4 * j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j] * v[j];
+        }
+        for (; i >= 0; i -= 4) { const double v = E[i]; s += v * v; }
+        for (i = blockn; i < n; ++i)
             if (((7 - (n - i)) & 3) == lane) { const double v = E[i]; s += v * v; }
     }
     return bcast(s, 0) + bcast(s, 1) + bcast(s, 2) + bcast(s, 3);
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
         return;
     }
     float4 *P = reinterpret_cast<float4 *>(lds);
-    double *Q = lds + 2 * (size_t)N, *E = Q + 9 * (size_t)N, *S = E + 2 * (size_t)N;
+    double *Q = lds + 2 * (size_t)N, *E = Q + 10 * (size_t)N, *S = E + 2 * (size_t)N;
     for (int i = lane; i < N; i += 64) P[i] = make_float4(a.x1[o0 + i], a.y1[o0 + i], a.x2[o0 + i], a.y2[o0 + i]);
 
     const int r = lane >> 3, c = lane & 7;
@@ -187,6 +204,10 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
     const double eps2_sq = a.eps2 * a.eps2;
     double mu = 0.0, jacTe_inf = 0.0, p_L2 = 0.0, Dp_L2 = DBL_MAX, p_eL2, pDp_eL2, ajj = 0.0;
     int nu = 2, stop = 0, nfev = 1, njev = 0, nlss = 0, k;
+#ifdef HOM_PROF
+    long long prof_acc[4] = {0, 0, 0, 0};
+    const long long prof_t0 = clock64();
+#endif
 
     __syncthreads();
     hom_eval<false>(P, N, p, Q, E, lane);
@@ -198,28 +219,59 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
     for (k = 0; k < a.itmax && !stop; ++k) {
         if (p_eL2 <= a.eps3) { stop = 6; break; }
         __syncthreads();
-        hom_eval<true>(P, N, p, Q, E, lane);
+        HOM_T(0, hom_eval<true>(P, N, p, Q, E, lane); __syncthreads())
         ++njev;
         __syncthreads();
+#ifdef HOM_PROF
+        const long long prof_ts = clock64();
+#endif
         if (lane < 29) {
+            // every lane reads both of its operand pairs for a group of points first, then adds the products in the
+            // reference's order; a structurally zero term multiplies the zero column and adds +0
+            const double *q0 = Q + (c0 >= 0 ? c0 : 9), *r0 = Q + (c0 >= 0 ? d0 : 9);
+            const double *q1 = Q + (c1 >= 0 ? c1 : 9), *r1 = Q + (c1 >= 0 ? d1 : 9);
             double res;
             if (small) {            // lm_core.c:217-237: rows from the last to the first, one running sum
                 double s = 0.0;
-                for (int pt = N - 1; pt >= 0; --pt) {
-                    const double *q = Q + (size_t)pt * 9;
-                    if (c1 >= 0) s += q[c1] * q[d1];
-                    if (c0 >= 0) s += q[c0] * q[d0];
+                int pt = N - 1;
+                for (; pt >= 7; pt -= 8) {
+                    double t0[8], t1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = (pt - j) * 10;
+                        t0[j] = q0[o] * r0[o]; t1[j] = q1[o] * r1[o];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s += t1[j]; s += t0[j]; }
+                }
+                for (; pt >= 0; --pt) {
+                    const int o = pt * 10;
+                    const double t0 = q0[o] * r0[o], t1 = q1[o] * r1[o];
+                    s += t1; s += t0;
                 }
                 res = s;
             } else {                // misc_core.c:80-132: 32-row partial sums; J^T e row by row (lm_core.c:246-254)
                 double tot = 0.0, part = 0.0;
                 for (int b0 = 0; b0 < N; b0 += 16) {
-                    const int be = b0 + 16 < N ? b0 + 16 : N;
                     if (!is_jte) part = 0.0;
-                    for (int pt = b0; pt < be; ++pt) {
-                        const double *q = Q + (size_t)pt * 9;
-                        if (c0 >= 0) part += q[c0] * q[d0];
-                        if (c1 >= 0) part += q[c1] * q[d1];
+                    if (b0 + 16 <= N) {
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            double t0[8], t1[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int o = (b0 + hh * 8 + j) * 10;
+                                t0[j] = q0[o] * r0[o]; t1[j] = q1[o] * r1[o];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { part += t0[j]; part += t1[j]; }
+                        }
+                    } else {
+                        for (int pt = b0; pt < N; ++pt) {
+                            const int o = pt * 10;
+                            part += q0[o] * r0[o];
+                            part += q1[o] * r1[o];
+                        }
                     }
                     if (!is_jte) tot += part;
                 }
@@ -227,6 +279,10 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
             }
             S[lane] = res;
         }
+#ifdef HOM_PROF
+        __syncthreads();
+        prof_acc[1] += clock64() - prof_ts;
+#endif
         __syncthreads();
         ajj = entry >= 0 ? S[entry] : 0.0;
 #pragma unroll
@@ -248,7 +304,8 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
         const double brow = S[21 + r];
         for (;;) {
             const double aug = (r == c) ? ajj + mu : ajj;
-            const bool ok = hom_lu_solve(aug, brow, lane, Dp);
+            bool ok;
+            HOM_T(3, ok = hom_lu_solve(aug, brow, lane, Dp))
             ++nlss;
             if (ok) {
                 Dp_L2 = 0.0;
@@ -257,10 +314,10 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
                 if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
                 if (Dp_L2 >= (p_L2 + a.eps2) / (1e-12 * 1e-12)) { stop = 4; break; }
                 __syncthreads();
-                hom_eval<false>(P, N, pDp, Q, E, lane);
+                HOM_T(0, hom_eval<false>(P, N, pDp, Q, E, lane); __syncthreads())
                 ++nfev;
                 __syncthreads();
-                pDp_eL2 = hom_norm2(E, n, lane);
+                HOM_T(2, pDp_eL2 = hom_norm2(E, n, lane))
                 if (!isfinite(pDp_eL2)) { stop = 7; break; }
                 double dL = 0.0;
 #pragma unroll
@@ -285,6 +342,12 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
     }
     if (k >= a.itmax && !stop) stop = 3;
 
+#ifdef HOM_PROF
+    if (lane == 0 && a.prof) {
+        for (int i = 0; i < 4; ++i) a.prof[(size_t)prob * 5 + i] = prof_acc[i];
+        a.prof[(size_t)prob * 5 + 4] = clock64() - prof_t0;
+    }
+#endif
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) Hp[i] = p[i];

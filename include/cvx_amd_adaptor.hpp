@@ -210,4 +210,61 @@ bool solve_handeye(const std::vector<Affine> &gripper_to_base, const std::vector
     return solve_nonlinear(Av, Bv, X, device, stream);
 }
 
+// ------------------------------------------------------------------------------------------
+// bool HomographyEstimator::solveLM(pts1, pts2, inliers, H)      homography.cpp:218-236
+// for a batch of views in one launch.  Point: anything with float members x, y (cv::Point2f); Mat3: operator()(r, c)
+// (Eigen::Matrix3d).  views[i] = {pts1, pts2, inliers}; H[i] in: the linear / RANSAC estimate, out: the refined one
+// with H(2,2) = 1.  max_iter = HomographyEstimator::Parameters::lm_params_.max_iter_ (the reference passes its
+// ftol_ too, but LMSolver::minimizeDer never reads it, lm.hpp:61).  Returns true like the reference.
+// ------------------------------------------------------------------------------------------
+template <class Point, class Mat3>
+bool homography_solve_lm_batch(const std::vector<const std::vector<Point> *> &pts1,
+                               const std::vector<const std::vector<Point> *> &pts2,
+                               const std::vector<const std::vector<size_t> *> &inliers, std::vector<Mat3> &H,
+                               int max_iter = 100, int device = 0, void *stream = nullptr) {
+    const size_t n = H.size();
+    if (pts1.size() != n || pts2.size() != n || inliers.size() != n) throw std::invalid_argument("homography batch: size mismatch");
+    if (n == 0) return true;
+    std::vector<int> off(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int)inliers[i]->size();
+    std::vector<float> x1(off[n]), y1(off[n]), x2(off[n]), y2(off[n]);
+    std::vector<double> h(9 * n);
+    for (size_t i = 0; i < n; ++i) {
+        int o = off[i];
+        for (size_t idx : *inliers[i]) {                       // homography.cpp:170-174
+            x1[o] = (*pts1[i])[idx].x; y1[o] = (*pts1[i])[idx].y;
+            x2[o] = (*pts2[i])[idx].x; y2[o] = (*pts2[i])[idx].y;
+            ++o;
+        }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) h[9 * i + 3 * r + c] = H[i](r, c);   // :229
+    }
+    cvx_homography *hh = nullptr;
+    check(cvx_homography_create((int)n, off.data(), x1.data(), y1.data(), x2.data(), y2.data(), device, stream, &hh),
+          "cvx_homography_create");
+    std::vector<int> ret(n);
+    const int st = cvx_homography_solve(hh, h.data(), max_iter, nullptr, nullptr, ret.data());
+    cvx_homography_destroy(hh);
+    check(st, "cvx_homography_solve");
+    for (size_t i = 0; i < n; ++i) {
+        if (ret[i] < 0 && inliers[i]->size() < 4) continue;    // levmar refuses 2N < 8 and leaves h alone; :233 then
+        for (int r = 0; r < 3; ++r)                            // rewrites the same numbers with H(2,2) = 1
+            for (int c = 0; c < 3; ++c) H[i](r, c) = h[9 * i + 3 * r + c];
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (inliers[i]->size() < 4) H[i](2, 2) = 1.0;
+    return true;
+}
+
+// the reference's single-view signature
+template <class Point, class Mat3>
+bool homography_solve_lm(const std::vector<Point> &pts1, const std::vector<Point> &pts2,
+                         const std::vector<size_t> &inliers, Mat3 &H, int max_iter = 100, int device = 0,
+                         void *stream = nullptr) {
+    std::vector<Mat3> Hs(1, H);
+    const bool ok = homography_solve_lm_batch<Point, Mat3>({&pts1}, {&pts2}, {&inliers}, Hs, max_iter, device, stream);
+    H = Hs[0];
+    return ok;
+}
+
 }  // namespace cvx_amd

@@ -1,7 +1,7 @@
 // Exercises include/cvx_amd_adaptor.hpp with stand-in structs that have the shape of the reference's
 // boundary types (CameraCalibration::Data calibration.hpp:18-26, CalibrationPattern::Marker
 // pattern.hpp:18-24, Eigen::Matrix4d / Affine3d): BASELINE config 1 through cvx_amd::refine and a
-// 30-pose hand-eye problem through cvx_amd::solve_handeye.  Prints one JSON line; tests/test_adaptor.py
+// 30-pose hand-eye problem through cvx_amd::solve_handeye, one view through cvx_amd::homography_solve_lm.  Prints one JSON line; tests/test_adaptor.py
 // compares it with the oracle.  Built by cvx_amd/csrc/Makefile (target adaptor_mock).
 #include <cstdio>
 #include <vector>
@@ -21,6 +21,11 @@ struct Mat4 {
     double operator()(int r, int c) const { return m[4 * c + r]; }
     Mat4 &matrix() { return *this; }
     const Mat4 &matrix() const { return *this; }
+};
+struct Mat3 {
+    double m[9];    // row-major here; only operator() is used
+    double &operator()(int r, int c) { return m[3 * r + c]; }
+    double operator()(int r, int c) const { return m[3 * r + c]; }
 };
 struct Camera {
     double fx_, fy_, cx_, cy_, d[5];
@@ -88,6 +93,36 @@ int main() {
     }
     std::printf("\"handeye_ok\": %d, \"X\": [", ok ? 1 : 0);
     for (int i = 0; i < 16; ++i) std::printf("%s%.17g", i ? ", " : "", X.m[i]);
+    std::printf("], ");
+
+    // HomographyEstimator::solveLM on view 0: board (x, y) -> image points, inliers = all but every 5th point,
+    // start = K [r1 r2 t] of the perturbed initial pose, normalised to H(2,2) = 1
+    std::vector<Pt2f> b1, b2;
+    std::vector<size_t> inl;
+    for (int o = off[0]; o < off[1]; ++o) {
+        b1.push_back({(float)xi[3 * pid[o]], (float)xi[3 * pid[o] + 1]});
+        b2.push_back({(float)ox[o], (float)oy[o]});
+        if ((o - off[0]) % 5) inl.push_back((size_t)(o - off[0]));
+    }
+    double R0[9];
+    cvx_angle_axis_to_rotation(&pi[0], R0);
+    Mat3 H;
+    const double K[9] = {ii[0], 0, ii[2], 0, ii[1], ii[3], 0, 0, 1};
+    const double M[9] = {R0[0], R0[3], pi[3], R0[1], R0[4], pi[4], R0[2], R0[5], pi[5]};   // [r1 r2 t] row-major
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) H(r, c) = K[3 * r] * M[c] + K[3 * r + 1] * M[3 + c] + K[3 * r + 2] * M[6 + c];
+    const double h22 = H(2, 2);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H(r, c) /= h22;
+    std::printf("\"hom_start\": [");
+    for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", H.m[i]);
+    try {
+        ok = cvx_amd::homography_solve_lm(b1, b2, inl, H);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 6;
+    }
+    std::printf("], \"hom_ok\": %d, \"hom\": [", ok ? 1 : 0);
+    for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", H.m[i]);
     std::printf("]}\n");
     return 0;
 }

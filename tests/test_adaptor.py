@@ -62,3 +62,12 @@ def test_adaptor_refine_and_handeye_match_oracle(orc):
     L.cvx_quat_trans_to_affine(cvx_amd.capi.pd(p.copy()), cvx_amd.capi.pd(M))
     assert out["handeye_ok"] == 1
     assert np.max(np.abs(np.array(out["X"]) - M)) < 1e-9
+    # homography: view 0, inliers = all but every 5th point, bit-exact against the oracle from the printed start
+    o0, o1 = d["view_off"][0], d["view_off"][1]
+    keep = [i for i in range(o1 - o0) if i % 5]
+    pid = d["point_id"][o0:o1][keep]
+    x1 = d["points_init"][pid, 0].astype(np.float32); y1 = d["points_init"][pid, 1].astype(np.float32)
+    x2 = d["obs_x"][o0:o1][keep].astype(np.float32); y2 = d["obs_y"][o0:o1][keep].astype(np.float32)
+    r, h, info = orc.homography_lm(x1, y1, x2, y2, out["hom_start"])
+    assert out["hom_ok"] == 1 and r > 0
+    assert out["hom"][:8] == h.tolist() and out["hom"][8] == 1.0
