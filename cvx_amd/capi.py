@@ -67,6 +67,12 @@ class CalibDesc(C.Structure):
                 ("device", C.c_int), ("stream", C.c_void_p)]
 
 
+class ToolBADesc(C.Structure):
+    _fields_ = [("n_views", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int64), ("view_off", ip), ("point_id", ip),
+                ("obs_x", dp), ("obs_y", dp), ("trans", dp), ("intrinsics", C.c_double * 9), ("huber", C.c_double),
+                ("device", C.c_int), ("stream", C.c_void_p)]
+
+
 class Damping(C.Structure):
     _fields_ = [("inv_radius", C.c_double), ("mu", C.c_double), ("min_diag", C.c_double), ("max_diag", C.c_double)]
 
@@ -122,6 +128,12 @@ SIGNATURES = {
     "cvx_handeye_pairs_fixed": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
     "cvx_handeye_pairs_moving": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, ip]),
     "cvx_handeye_linear": (C.c_int, [C.c_int, C.c_int, dp, dp, dp]),
+    "cvx_toolba_create": (C.c_int, [C.POINTER(ToolBADesc), C.POINTER(C.c_void_p)]),
+    "cvx_toolba_destroy": (None, [C.c_void_p]),
+    "cvx_lm_options_toolba": (None, [C.POINTER(LMOptions)]),
+    "cvx_toolba_cost": (C.c_int, [C.c_void_p, dp, dp, dp]),
+    "cvx_toolba_normal_eq": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp]),
+    "cvx_toolba_solve": (C.c_int, [C.c_void_p, dp, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]),
     "cvx_homography_create": (C.c_int, [C.c_int, ip, fp, fp, fp, fp, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "cvx_homography_destroy": (None, [C.c_void_p]),
     "cvx_homography_solve": (C.c_int, [C.c_void_p, dp, C.c_int, dp, dp, ip]),
@@ -182,5 +194,5 @@ def pi(a):
 def options(kind="refine"):
     o = LMOptions()
     {"refine": lib().cvx_lm_options_refine, "handeye": lib().cvx_lm_options_handeye,
-     "levmar": lib().cvx_lm_options_levmar}[kind](C.byref(o))
+     "levmar": lib().cvx_lm_options_levmar, "toolba": lib().cvx_lm_options_toolba}[kind](C.byref(o))
     return o

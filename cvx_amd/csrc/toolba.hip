@@ -1,0 +1,401 @@
+// Tool-level bundle adjustment: handle, evaluator and C ABI around toolba_kernels.h.
+// Replaces the body of bundleAdjustment between "p[7] packed" and "pose rebuilt"
+// (/root/reference/modules/calib/tools/hand_eye_registration.cpp:158-229, camera_ba.cpp:160-231): the device
+// reduces the observations to the arrowhead normal equations; the host eliminates the 3x3 point blocks, solves
+// the 6x6 pose system and runs the trust-region loop of lm_driver.cpp with the options of :201-210.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "lm_driver.h"
+#include "toolba_kernels.h"
+
+using namespace cvxt;
+
+struct cvx_toolba {
+    int V = 0, P = 0, device = 0, n_jobs = 0;
+    long long N = 0;
+    double huber = 1.0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    double *d_obs = nullptr;       // ox | oy, point-major
+    int *d_view = nullptr, *d_jobs = nullptr, *d_job_first = nullptr;
+    double *d_trans = nullptr, *d_params = nullptr, *d_intr = nullptr, *d_partial = nullptr, *d_cpartial = nullptr, *d_out = nullptr;
+    double *h_out = nullptr, *h_params = nullptr;
+    ~cvx_toolba() {
+        (void)hipSetDevice(device);
+        for (void *p : {(void *)d_obs, (void *)d_view, (void *)d_jobs, (void *)d_job_first, (void *)d_trans,
+                        (void *)d_params, (void *)d_intr, (void *)d_partial, (void *)d_cpartial, (void *)d_out})
+            if (p) (void)hipFree(p);
+        if (h_out) (void)hipHostFree(h_out);
+        if (h_params) (void)hipHostFree(h_params);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+TbaArgs make_args(cvx_toolba *h) {
+    TbaArgs a;
+    const size_t n = (size_t)std::max<long long>(h->N, 1);
+    a.ox = h->d_obs; a.oy = h->d_obs + n; a.view = h->d_view; a.trans = h->d_trans; a.params = h->d_params;
+    a.intr = h->d_intr; a.huber = h->huber;
+    a.job_point = h->d_jobs; a.job_start = h->d_jobs + h->n_jobs; a.job_count = h->d_jobs + 2 * h->n_jobs;
+    a.partial = h->d_partial;
+    return a;
+}
+
+int upload(cvx_toolba *h, const double *x) {
+    std::memcpy(h->h_params, x, sizeof(double) * (7 + 3 * (size_t)h->P));
+    CVX_HIP(hipMemcpyAsync(h->d_params, h->h_params, sizeof(double) * (7 + 3 * (size_t)h->P), hipMemcpyHostToDevice, h->stream));
+    return CVX_OK;
+}
+
+// 1/2 sum rho at x
+int device_cost(cvx_toolba *h, const double *x, double *cost) {
+    int st = upload(h, x);
+    if (st) return st;
+    if (h->n_jobs > 0) {
+        TbaArgs a = make_args(h);
+        a.partial = h->d_cpartial;
+        hipLaunchKernelGGL(k_tba_cost, dim3(h->n_jobs), dim3(TBA_THREADS), 0, h->stream, a);
+        CVX_HIP(hipGetLastError());
+    }
+    // the scalar lives behind the per-point blocks, which stay valid across rejected steps
+    const size_t slot = (size_t)h->P * TBA_ACC;
+    hipLaunchKernelGGL(k_tba_cost_final, dim3(1), dim3(TBA_THREADS), 0, h->stream, h->d_cpartial, h->n_jobs, h->d_out + slot);
+    CVX_HIP(hipGetLastError());
+    CVX_HIP(hipMemcpyAsync(h->h_out + slot, h->d_out + slot, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    *cost = 0.5 * h->h_out[slot];
+    return CVX_OK;
+}
+
+// per-point sums [P][TBA_ACC] at x -> h_out
+int device_blocks(cvx_toolba *h, const double *x) {
+    int st = upload(h, x);
+    if (st) return st;
+    if (h->n_jobs > 0) {
+        hipLaunchKernelGGL(k_tba_normal_eq, dim3(h->n_jobs), dim3(TBA_THREADS), 0, h->stream, make_args(h));
+        CVX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_tba_reduce, dim3(h->P), dim3(64), 0, h->stream, h->d_partial, h->d_job_first, h->d_out);
+    CVX_HIP(hipGetLastError());
+    CVX_HIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * TBA_ACC * (size_t)h->P, hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+void quaternion_plus(const double x[4], const double d[3], double out[4]) {     // Ceres QuaternionParameterization::Plus
+    const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n > 0.0) {
+        const double sn = std::sin(n) / n;
+        const double q[4] = {std::cos(n), sn * d[0], sn * d[1], sn * d[2]};
+        out[0] = q[0] * x[0] - q[1] * x[1] - q[2] * x[2] - q[3] * x[3];
+        out[1] = q[0] * x[1] + q[1] * x[0] + q[2] * x[3] - q[3] * x[2];
+        out[2] = q[0] * x[2] - q[1] * x[3] + q[2] * x[0] + q[3] * x[1];
+        out[3] = q[0] * x[3] + q[1] * x[2] - q[2] * x[1] + q[3] * x[0];
+    } else {
+        for (int i = 0; i < 4; ++i) out[i] = x[i];
+    }
+}
+
+// 3x3 SPD solve helpers: A (upper triangle a00 a01 a02 a11 a12 a22) -> Cholesky factor in place; false if not PD
+bool chol3(double a[6]) {
+    if (!(a[0] > 0.0)) return false;
+    const double l00 = std::sqrt(a[0]), l10 = a[1] / l00, l20 = a[2] / l00;
+    const double d1 = a[3] - l10 * l10;
+    if (!(d1 > 0.0)) return false;
+    const double l11 = std::sqrt(d1), l21 = (a[4] - l20 * l10) / l11;
+    const double d2 = a[5] - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) return false;
+    a[0] = l00; a[1] = l10; a[2] = l20; a[3] = l11; a[4] = l21; a[5] = std::sqrt(d2);
+    return true;
+}
+void chol3_solve(const double l[6], double b[3]) {
+    b[0] /= l[0];
+    b[1] = (b[1] - l[1] * b[0]) / l[3];
+    b[2] = (b[2] - l[2] * b[0] - l[4] * b[1]) / l[5];
+    b[2] /= l[5];
+    b[1] = (b[1] - l[4] * b[2]) / l[3];
+    b[0] = (b[0] - l[1] * b[1] - l[2] * b[2]) / l[0];
+}
+
+class ToolBAEvaluator : public cvx::Evaluator {
+public:
+    ToolBAEvaluator(cvx_toolba *h_, const double *p, const double *pts) : h(h_), P(h_->P), nf(6 + 3 * h_->P), ng(7 + 3 * h_->P) {
+        x.resize(ng); xc.resize(ng); s2.assign(nf, 1.0); diag.resize(nf); grad.resize(nf); delta.resize(nf); D.resize(nf);
+        std::memcpy(x.data(), p, 7 * sizeof(double));
+        std::memcpy(x.data() + 7, pts, sizeof(double) * 3 * (size_t)P);
+    }
+    cvx_toolba *h;
+    int P, nf, ng;
+    std::vector<double> x, xc, s2, diag, grad, delta, D;
+    double Hpp[36], cost = 0;
+    bool lin_valid = false, projected = true;
+
+    void set_strategy(int strategy) override { projected = (strategy == 0); }
+
+    const double *blk(int p) const { return h->h_out + (size_t)p * TBA_ACC; }
+
+    int linearize() {
+        if (lin_valid) return CVX_OK;
+        int st = device_blocks(h, x.data());
+        if (st) return st;
+        double up[28];
+        for (int k = 0; k < 28; ++k) up[k] = 0.0;
+        double c = 0.0;
+        for (int p = 0; p < P; ++p) {                       // pose block = sum over points, fixed order
+            const double *b = blk(p);
+            for (int k = 0; k < 27; ++k) up[k] += b[k];
+            c += b[54];
+            diag[6 + 3 * p] = b[45]; diag[6 + 3 * p + 1] = b[48]; diag[6 + 3 * p + 2] = b[50];
+            for (int k = 0; k < 3; ++k) grad[6 + 3 * p + k] = b[51 + k];
+        }
+        int e = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { Hpp[a * 6 + b] = up[e]; Hpp[b * 6 + a] = up[e]; ++e; }
+        for (int a = 0; a < 6; ++a) { diag[a] = Hpp[a * 6 + a]; grad[a] = up[21 + a]; }
+        cost = 0.5 * c;
+        lin_valid = true;
+        return CVX_OK;
+    }
+
+    void plus(const double *d, double *out) const {
+        quaternion_plus(x.data(), d, out);
+        for (int a = 0; a < 3; ++a) out[4 + a] = x[4 + a] + d[3 + a];
+        for (int a = 0; a < 3 * P; ++a) out[7 + a] = x[7 + a] + d[6 + a];
+    }
+
+    double grad_norm() {
+        double m = 0;
+        if (projected) {                                    // Ceres: max-norm of x - Plus(x, -g)
+            double d[3] = {-grad[0], -grad[1], -grad[2]}, q[4];
+            quaternion_plus(x.data(), d, q);
+            for (int i = 0; i < 4; ++i) m = std::max(m, std::fabs(x[i] - q[i]));
+            for (int a = 3; a < nf; ++a) m = std::max(m, std::fabs(grad[a]));
+        } else {
+            for (int a = 0; a < nf; ++a) m = std::max(m, std::fabs(grad[a]));
+        }
+        return m;
+    }
+
+    cvx::InitInfo init(bool jacobi) override {
+        cvx::InitInfo out;
+        out.status = linearize();
+        if (out.status) return out;
+        double dm = 0;
+        for (int a = 0; a < nf; ++a) {
+            if (jacobi) { const double s = 1.0 / (1.0 + std::sqrt(diag[a])); s2[a] = s * s; }
+            else s2[a] = 1.0;
+            dm = std::max(dm, diag[a]);
+        }
+        out.cost = cost; out.grad_max = grad_norm(); out.diag_max = dm;
+        return out;
+    }
+
+    // (H + D) delta = -g by eliminating the point blocks
+    bool solve_arrowhead() {
+        double S[36], b[6];
+        std::memcpy(S, Hpp, sizeof S);
+        for (int a = 0; a < 6; ++a) { S[a * 6 + a] += D[a]; b[a] = -grad[a]; }
+        std::vector<double> L((size_t)6 * P);
+        for (int p = 0; p < P; ++p) {
+            const double *k = blk(p);
+            double *l = L.data() + 6 * (size_t)p;
+            l[0] = k[45] + D[6 + 3 * p]; l[1] = k[46]; l[2] = k[47];
+            l[3] = k[48] + D[6 + 3 * p + 1]; l[4] = k[49]; l[5] = k[50] + D[6 + 3 * p + 2];
+            if (!chol3(l)) return false;
+            double y[6][3];                                  // rows of W (U + D)^-1
+            for (int a = 0; a < 6; ++a) {
+                for (int c = 0; c < 3; ++c) y[a][c] = k[27 + 3 * a + c];
+                chol3_solve(l, y[a]);
+            }
+            for (int a = 0; a < 6; ++a) {
+                for (int c = 0; c < 6; ++c)
+                    S[a * 6 + c] -= y[a][0] * k[27 + 3 * c] + y[a][1] * k[27 + 3 * c + 1] + y[a][2] * k[27 + 3 * c + 2];
+                b[a] += y[a][0] * k[51] + y[a][1] * k[52] + y[a][2] * k[53];
+            }
+        }
+        if (!cvx::host_cholesky_solve(6, S, b)) return false;
+        for (int a = 0; a < 6; ++a) delta[a] = b[a];
+        for (int p = 0; p < P; ++p) {
+            const double *k = blk(p);
+            double r[3];
+            for (int c = 0; c < 3; ++c) {
+                double s = k[51 + c];
+                for (int a = 0; a < 6; ++a) s += k[27 + 3 * a + c] * delta[a];
+                r[c] = -s;
+            }
+            chol3_solve(L.data() + 6 * (size_t)p, r);
+            for (int c = 0; c < 3; ++c) delta[6 + 3 * p + c] = r[c];
+        }
+        for (int a = 0; a < nf; ++a) if (!std::isfinite(delta[a])) return false;
+        return true;
+    }
+
+    cvx::StepInfo try_step(const cvx_damping &d, double gtol, bool gradient_only) override {
+        cvx::StepInfo out;
+        out.status = linearize();
+        if (out.status) return out;
+        out.cost = cost; out.grad_max = grad_norm();
+        if (out.grad_max <= gtol) { out.grad_converged = true; return out; }
+        if (gradient_only) return out;
+        for (int a = 0; a < nf; ++a) {
+            double c = s2[a] * diag[a];
+            c = std::min(std::max(c, d.min_diag), d.max_diag);
+            D[a] = c * d.inv_radius / s2[a] + d.mu;
+        }
+        if (!solve_arrowhead()) { out.ok = false; return out; }
+        plus(delta.data(), xc.data());
+        double cand = 0;
+        out.status = device_cost(h, xc.data(), &cand);
+        if (out.status) return out;
+        double m = 0, sn = 0, xn = 0, d2 = 0;
+        for (int a = 0; a < nf; ++a) { m += delta[a] * (D[a] * delta[a] - grad[a]); d2 += delta[a] * delta[a]; }
+        for (int i = 0; i < ng; ++i) { sn += (x[i] - xc[i]) * (x[i] - xc[i]); xn += x[i] * x[i]; }
+        out.cand_cost = cand; out.model_change = 0.5 * m;
+        out.step_norm2 = projected ? sn : d2;
+        out.x_norm2 = xn; out.free_norm2 = xn;
+        out.ok = std::isfinite(out.model_change);
+        return out;
+    }
+
+    int accept() override {
+        x = xc;
+        lin_valid = false;
+        return CVX_OK;
+    }
+
+};
+
+}  // namespace
+
+extern "C" void cvx_lm_options_toolba(cvx_lm_options *o) {     // hand_eye_registration.cpp:201-210
+    cvx_lm_options_refine(o);
+    o->nonmonotonic = 0;
+    o->function_tolerance = o->gradient_tolerance = o->parameter_tolerance = 1e-20;
+}
+
+extern "C" int cvx_toolba_create(const cvx_toolba_desc *d, cvx_toolba **out) {
+    if (!out) return CVX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!d || d->n_views < 0 || d->n_points <= 0 || d->n_obs < 0 || !d->view_off || (d->n_views > 0 && !d->trans) ||
+        (d->n_obs > 0 && (!d->point_id || !d->obs_x || !d->obs_y)))
+        return CVX_ERR_INVALID_ARG;
+    if (d->n_points > CVX_MAX_POINTS) { cvx::set_last_error("toolba: more than CVX_MAX_POINTS board points"); return CVX_ERR_UNSUPPORTED; }
+    if (d->view_off[0] != 0 || d->view_off[d->n_views] != d->n_obs) { cvx::set_last_error("toolba: view_off does not span n_obs"); return CVX_ERR_INVALID_ARG; }
+    const int V = d->n_views, P = d->n_points;
+    const long long N = d->n_obs;
+    // point-major order: observations of point 0 (by view), then point 1, ...
+    std::vector<long long> first((size_t)P + 1, 0);
+    for (int v = 0; v < V; ++v) {
+        if (d->view_off[v + 1] < d->view_off[v]) return CVX_ERR_INVALID_ARG;
+        for (int o = d->view_off[v]; o < d->view_off[v + 1]; ++o) {
+            const int p = d->point_id[o];
+            if (p < 0 || p >= P) { cvx::set_last_error("toolba: point id out of range"); return CVX_ERR_INVALID_ARG; }
+            ++first[(size_t)p + 1];
+        }
+    }
+    for (int p = 0; p < P; ++p) first[(size_t)p + 1] += first[p];
+    const size_t n = (size_t)std::max<long long>(N, 1);
+    std::vector<double> obs(2 * n, 0.0);
+    std::vector<int> view(n, 0);
+    {
+        std::vector<long long> cur(first.begin(), first.end() - 1);
+        for (int v = 0; v < V; ++v)
+            for (int o = d->view_off[v]; o < d->view_off[v + 1]; ++o) {
+                const long long k = cur[d->point_id[o]]++;
+                obs[k] = d->obs_x[o]; obs[n + k] = d->obs_y[o]; view[k] = v;
+            }
+    }
+    std::vector<int> jp, js, jc, jfirst((size_t)P + 1, 0);
+    for (int p = 0; p < P; ++p) {
+        jfirst[p] = (int)jp.size();
+        for (long long s = first[p]; s < first[(size_t)p + 1]; s += TBA_CHUNK) {
+            jp.push_back(p); js.push_back((int)s); jc.push_back((int)std::min<long long>(TBA_CHUNK, first[(size_t)p + 1] - s));
+        }
+    }
+    jfirst[P] = (int)jp.size();
+    const int n_jobs = (int)jp.size();
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { cvx::set_last_error("no HIP device visible"); return CVX_ERR_NO_DEVICE; }
+    if (d->device < 0 || d->device >= ndev) return CVX_ERR_NO_DEVICE;
+    CVX_HIP(hipSetDevice(d->device));
+    std::unique_ptr<cvx_toolba> h(new cvx_toolba);
+    h->V = V; h->P = P; h->N = N; h->device = d->device; h->n_jobs = n_jobs; h->huber = d->huber;
+    if (d->stream) h->stream = (hipStream_t)d->stream;
+    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    std::vector<int> jobs(3 * (size_t)std::max(n_jobs, 1), 0);
+    for (int j = 0; j < n_jobs; ++j) { jobs[j] = jp[j]; jobs[n_jobs + j] = js[j]; jobs[2 * (size_t)n_jobs + j] = jc[j]; }
+    const size_t nv = (size_t)std::max(V, 1);
+    CVX_HIP(hipMalloc((void **)&h->d_obs, 2 * n * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_view, n * sizeof(int)));
+    CVX_HIP(hipMalloc((void **)&h->d_jobs, jobs.size() * sizeof(int)));
+    CVX_HIP(hipMalloc((void **)&h->d_job_first, ((size_t)P + 1) * sizeof(int)));
+    CVX_HIP(hipMalloc((void **)&h->d_trans, nv * 12 * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_params, (7 + 3 * (size_t)P) * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_intr, 9 * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_partial, (size_t)std::max(n_jobs, 1) * TBA_ACC * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_cpartial, (size_t)std::max(n_jobs, 1) * sizeof(double)));
+    CVX_HIP(hipMalloc((void **)&h->d_out, ((size_t)P * TBA_ACC + 8) * sizeof(double)));
+    CVX_HIP(hipHostMalloc((void **)&h->h_out, ((size_t)P * TBA_ACC + 8) * sizeof(double), hipHostMallocDefault));
+    CVX_HIP(hipHostMalloc((void **)&h->h_params, (7 + 3 * (size_t)P) * sizeof(double), hipHostMallocDefault));
+    CVX_HIP(hipMemcpyAsync(h->d_obs, obs.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipMemcpyAsync(h->d_view, view.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipMemcpyAsync(h->d_job_first, jfirst.data(), jfirst.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (V > 0) CVX_HIP(hipMemcpyAsync(h->d_trans, d->trans, (size_t)V * 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipMemcpyAsync(h->d_intr, d->intrinsics, 9 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    *out = h.release();
+    return CVX_OK;
+}
+
+extern "C" void cvx_toolba_destroy(cvx_toolba *h) { delete h; }
+
+extern "C" int cvx_toolba_cost(cvx_toolba *h, const double p[7], const double *points, double *cost) {
+    if (!h || !p || !points || !cost) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    std::vector<double> x(7 + 3 * (size_t)h->P);
+    std::memcpy(x.data(), p, 7 * sizeof(double));
+    std::memcpy(x.data() + 7, points, sizeof(double) * 3 * (size_t)h->P);
+    return device_cost(h, x.data(), cost);
+}
+
+extern "C" int cvx_toolba_normal_eq(cvx_toolba *h, const double p[7], const double *points, double Hpp[36], double gp[6],
+                                    double *W, double *U, double *gx, double *cost) {
+    if (!h || !p || !points) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    ToolBAEvaluator ev(h, p, points);
+    int st = ev.linearize();
+    if (st) return st;
+    if (Hpp) std::memcpy(Hpp, ev.Hpp, sizeof ev.Hpp);
+    if (gp) for (int a = 0; a < 6; ++a) gp[a] = ev.grad[a];
+    for (int q = 0; q < h->P; ++q) {
+        const double *b = ev.blk(q);
+        if (W) for (int k = 0; k < 18; ++k) W[18 * (size_t)q + k] = b[27 + k];
+        if (U) {
+            double *u = U + 9 * (size_t)q;
+            u[0] = b[45]; u[1] = u[3] = b[46]; u[2] = u[6] = b[47]; u[4] = b[48]; u[5] = u[7] = b[49]; u[8] = b[50];
+        }
+        if (gx) for (int k = 0; k < 3; ++k) gx[3 * (size_t)q + k] = b[51 + k];
+    }
+    if (cost) *cost = ev.cost;
+    return CVX_OK;
+}
+
+extern "C" int cvx_toolba_solve(cvx_toolba *h, double p[7], double *points, const cvx_lm_options *opt,
+                                cvx_lm_summary *summary) {
+    if (!h || !p || !points || !opt || !summary) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    ToolBAEvaluator ev(h, p, points);
+    int st = cvx::lm_minimize(ev, *opt, *summary);
+    std::memcpy(p, ev.x.data(), 7 * sizeof(double));
+    std::memcpy(points, ev.x.data() + 7, sizeof(double) * 3 * (size_t)h->P);
+    return st;
+}

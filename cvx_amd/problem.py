@@ -281,3 +281,48 @@ class HomographyBatch:
         H = np.zeros((self.n, 9)); info = np.zeros((self.n, 10)); ret = np.zeros(self.n, np.int32)
         check(lib().cvx_homography_get(self.h, pd(H), pd(info), pi(ret)), "cvx_homography_get")
         return H, info, ret
+
+
+class ToolBA:
+    """cvx_toolba handle: bundleAdjustment of tools/hand_eye_registration.cpp:144-238 on one GPU."""
+
+    def __init__(self, view_off, point_id, obs_x, obs_y, trans, intr, n_points, huber=1.0, device=0, stream=None):
+        self.view_off = i32(view_off); self.point_id = i32(point_id)
+        self.obs_x = f64(obs_x); self.obs_y = f64(obs_y)
+        self.trans = f64(np.asarray(trans, dtype=np.float64).reshape(-1, 12))
+        self.V, self.N, self.P = len(self.view_off) - 1, len(self.point_id), int(n_points)
+        d = capi.ToolBADesc(self.V, self.P, self.N, pi(self.view_off), pi(self.point_id), pd(self.obs_x), pd(self.obs_y),
+                            pd(self.trans), (C.c_double * 9)(*[float(v) for v in intr]), float(huber), int(device),
+                            C.c_void_p(stream) if stream else None)
+        self.h = C.c_void_p()
+        check(lib().cvx_toolba_create(C.byref(d), C.byref(self.h)), "cvx_toolba_create")
+
+    def close(self):
+        if self.h:
+            lib().cvx_toolba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cost(self, p, points):
+        p, points = f64(p), f64(points); c = C.c_double()
+        check(lib().cvx_toolba_cost(self.h, pd(p), pd(points), C.byref(c)), "cvx_toolba_cost")
+        return c.value
+
+    def normal_eq(self, p, points):
+        """-> Hpp[6,6], gp[6], W[P,6,3], U[P,3,3], gx[P,3], cost"""
+        p, points = f64(p), f64(points)
+        Hpp = np.zeros((6, 6)); gp = np.zeros(6); W = np.zeros((self.P, 6, 3)); U = np.zeros((self.P, 3, 3))
+        gx = np.zeros((self.P, 3)); c = C.c_double()
+        check(lib().cvx_toolba_normal_eq(self.h, pd(p), pd(points), pd(Hpp), pd(gp), pd(W), pd(U), pd(gx), C.byref(c)),
+              "cvx_toolba_normal_eq")
+        return Hpp, gp, W, U, gx, c.value
+
+    def solve(self, p, points, options):
+        p, points = f64(p).copy(), f64(points).copy(); s = capi.LMSummary()
+        check(lib().cvx_toolba_solve(self.h, pd(p), pd(points), C.byref(options), C.byref(s)), "cvx_toolba_solve")
+        return p, points, s

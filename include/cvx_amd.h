@@ -243,6 +243,39 @@ int cvx_handeye_pairs_moving(int n, const double *gripper_to_base, const double 
 int cvx_handeye_linear(int method, int n, const double *A, const double *B, double X[16]);
 
 /* ------------------------------------------------------------------------ */
+/* Tool-level bundle adjustment                         */
+/* ------------------------------------------------------------------------ */
+/* bundleAdjustment of tools/hand_eye_registration.cpp:144-238 (= tools/camera_ba.cpp:146-240): one global pose
+ * p = {q.w,q.x,q.y,q.z,t} with QuaternionParameterization (:153-158,196-199), free board points (:161-166,187),
+ * constant intrinsics, the fixed rigid transform gripper_to_base[i] applied to the board point before the pose
+ * (functor :48-141), ceres::HuberLoss(1.0) on every residual block (:168,184), options :201-210. */
+typedef struct cvx_toolba cvx_toolba;
+typedef struct {
+    int n_views, n_points;
+    int64_t n_obs;
+    const int *view_off;      /* [n_views + 1] */
+    const int *point_id;      /* [n_obs] Marker::id_ */
+    const double *obs_x;      /* [n_obs] Marker::pt_ promoted to double (cv::Point2d img_, :51) */
+    const double *obs_y;
+    const double *trans;      /* [n_views][12]: top 3 rows of gripper_to_base[i].matrix(), row-major */
+    double intrinsics[9];     /* fx,fy,cx,cy,k1,k2,k3,p1,p2 read from the PinholeCamera (:67-77) */
+    double huber;             /* 1.0 in the reference; <= 0: no loss function */
+    int device;
+    void *stream;
+} cvx_toolba_desc;
+int cvx_toolba_create(const cvx_toolba_desc *desc, cvx_toolba **out);
+void cvx_toolba_destroy(cvx_toolba *h);
+void cvx_lm_options_toolba(cvx_lm_options *o);   /* hand_eye_registration.cpp:201-210 */
+/* 1/2 sum rho(|r|^2), what Problem::Evaluate returns at :222 */
+int cvx_toolba_cost(cvx_toolba *h, const double p[7], const double *points, double *cost);
+/* robustified normal equations over the tangent space, as arrowhead blocks: Hpp[36], gp[6], W[n_points][6][3],
+ * U[n_points][3][3], gx[n_points][3]; any may be NULL */
+int cvx_toolba_normal_eq(cvx_toolba *h, const double p[7], const double *points, double Hpp[36], double gp[6],
+                         double *W, double *U, double *gx, double *cost);
+/* ceres::Solve of :213-214; p and points in/out (the caller inverts the pose as :229-230 does) */
+int cvx_toolba_solve(cvx_toolba *h, double p[7], double *points, const cvx_lm_options *opt, cvx_lm_summary *summary);
+
+/* ------------------------------------------------------------------------ */
 /* Batched homography refinement                        */
 /* ------------------------------------------------------------------------ */
 /* HomographyEstimator::solveLM (homography.cpp:218-236) for n_problems independent views in one launch:

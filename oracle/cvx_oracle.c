@@ -1251,3 +1251,208 @@ int orc_homography_lm(void *engine, int n, const float *x1, const float *y1, con
     }
     return orc_lm_nielsen_der(hom_func, hom_jac, h, NULL, 8, 2 * n, itmax, opts, info, &c);
 }
+
+/* ======================================================================== */
+/* tool-level bundle adjustment: hand_eye_registration.cpp:48-238             */
+/* ======================================================================== */
+/* ceres::QuaternionRotatePoint (Ceres rotation.h, un-vendored: restated from the published 1.x source): the
+ * quaternion is normalised, then UnitQuaternionRotatePoint's expanded polynomial form. */
+static void d_quaternion_rotate_point(const dual q[4], const dual pt[3], dual out[3]) {
+    dual n2 = d_add(d_add(d_mul(q[0], q[0]), d_mul(q[1], q[1])), d_add(d_mul(q[2], q[2]), d_mul(q[3], q[3])));
+    dual sc = d_div(d_const(1.0), d_sqrt(n2));
+    dual u[4] = { d_mul(q[0], sc), d_mul(q[1], sc), d_mul(q[2], sc), d_mul(q[3], sc) };
+    dual zero = d_const(0.0), two = d_const(2.0);
+    dual t2 = d_mul(u[0], u[1]), t3 = d_mul(u[0], u[2]), t4 = d_mul(u[0], u[3]);
+    dual t5 = d_sub(zero, d_mul(u[1], u[1])), t6 = d_mul(u[1], u[2]), t7 = d_mul(u[1], u[3]);
+    dual t8 = d_sub(zero, d_mul(u[2], u[2])), t9 = d_mul(u[2], u[3]), t1 = d_sub(zero, d_mul(u[3], u[3]));
+    out[0] = d_add(d_mul(two, d_add(d_add(d_mul(d_add(t8, t1), pt[0]), d_mul(d_sub(t6, t4), pt[1])), d_mul(d_add(t3, t7), pt[2]))), pt[0]);
+    out[1] = d_add(d_mul(two, d_add(d_add(d_mul(d_add(t4, t6), pt[0]), d_mul(d_add(t5, t1), pt[1])), d_mul(d_sub(t9, t2), pt[2]))), pt[1]);
+    out[2] = d_add(d_mul(two, d_add(d_add(d_mul(d_sub(t7, t3), pt[0]), d_mul(d_add(t2, t9), pt[1])), d_mul(d_add(t5, t8), pt[2]))), pt[2]);
+}
+
+void orc_toolba_autodiff(const double intr[9], const double trans[12], const double q[4], const double t[3],
+                         const double X[3], double ox, double oy, double r[2], double Jq[8], double Jt[6], double Jx[6]) {
+    dual dq[4], dt[3], dX[3], Xt[3], x[3];
+    for (int i = 0; i < 4; ++i) dq[i] = d_var(q[i], i);
+    for (int i = 0; i < 3; ++i) dt[i] = d_var(t[i], 4 + i);
+    for (int i = 0; i < 3; ++i) dX[i] = d_var(X[i], 7 + i);
+    for (int i = 0; i < 3; ++i)      /* C = trans_ * (X, 1), hand_eye_registration.cpp:82-92 */
+        Xt[i] = d_add(d_add(d_add(d_mul(d_const(trans[4 * i]), dX[0]), d_mul(d_const(trans[4 * i + 1]), dX[1])),
+                            d_mul(d_const(trans[4 * i + 2]), dX[2])), d_const(trans[4 * i + 3]));
+    d_quaternion_rotate_point(dq, Xt, x);
+    for (int i = 0; i < 3; ++i) x[i] = d_add(x[i], dt[i]);
+    dual xn = d_div(x[0], x[2]), yn = d_div(x[1], x[2]);
+    dual two = d_const(2.0);
+    dual k1 = d_const(intr[ORC_K1]), k2 = d_const(intr[ORC_K2]), k3 = d_const(intr[ORC_K3]);
+    dual p1 = d_const(intr[ORC_P1]), p2 = d_const(intr[ORC_P2]);
+    dual r2 = d_add(d_mul(xn, xn), d_mul(yn, yn));
+    dual r4 = d_mul(r2, r2);
+    dual r6 = d_mul(r4, r2);
+    dual rc = d_add(d_add(d_add(d_const(1.0), d_mul(k1, r2)), d_mul(k2, r4)), d_mul(k3, r6));
+    dual xd = d_add(d_add(d_mul(xn, rc), d_mul(d_mul(d_mul(two, p1), xn), yn)), d_mul(p2, d_add(r2, d_mul(d_mul(two, xn), xn))));
+    dual yd = d_add(d_add(d_mul(yn, rc), d_mul(d_mul(d_mul(two, p2), xn), yn)), d_mul(p1, d_add(r2, d_mul(d_mul(two, yn), yn))));
+    dual e[2] = { d_sub(d_add(d_mul(d_const(intr[ORC_FX]), xd), d_const(intr[ORC_CX])), d_const(ox)),
+                  d_sub(d_add(d_mul(d_const(intr[ORC_FY]), yd), d_const(intr[ORC_CY])), d_const(oy)) };
+    for (int k = 0; k < 2; ++k) {
+        r[k] = e[k].v;
+        if (Jq) for (int i = 0; i < 4; ++i) Jq[k * 4 + i] = e[k].d[i];
+        if (Jt) for (int i = 0; i < 3; ++i) Jt[k * 3 + i] = e[k].d[4 + i];
+        if (Jx) for (int i = 0; i < 3; ++i) Jx[k * 3 + i] = e[k].d[7 + i];
+    }
+}
+
+void orc_toolba_analytic(const double intr[9], const double trans[12], const double q[4], const double t[3],
+                         const double X[3], double ox, double oy, double r[2], double Jq[8], double Jt[6], double Jx[6]) {
+    double p[3];
+    for (int i = 0; i < 3; ++i) p[i] = trans[4 * i] * X[0] + trans[4 * i + 1] * X[1] + trans[4 * i + 2] * X[2] + trans[4 * i + 3];
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const double sc = 1.0 / sqrt(n2);
+    const double u0 = q[0] * sc, u1 = q[1] * sc, u2 = q[2] * sc, u3 = q[3] * sc;
+    const double t2 = u0 * u1, t3 = u0 * u2, t4 = u0 * u3, t5 = -u1 * u1, t6 = u1 * u2, t7 = u1 * u3;
+    const double t8 = -u2 * u2, t9 = u2 * u3, t1 = -u3 * u3;
+    /* R - I, halved (the published polynomial form) */
+    const double M[9] = { t8 + t1, t6 - t4, t3 + t7,  t4 + t6, t5 + t1, t9 - t2,  t7 - t3, t2 + t9, t5 + t8 };
+    double xc[3];
+    for (int i = 0; i < 3; ++i) xc[i] = 2.0 * (M[3 * i] * p[0] + M[3 * i + 1] * p[1] + M[3 * i + 2] * p[2]) + p[i] + t[i];
+    const double fx = intr[ORC_FX], fy = intr[ORC_FY], cx = intr[ORC_CX], cy = intr[ORC_CY];
+    const double k1 = intr[ORC_K1], k2 = intr[ORC_K2], k3 = intr[ORC_K3], p1 = intr[ORC_P1], p2 = intr[ORC_P2];
+    const double xn = xc[0] / xc[2], yn = xc[1] / xc[2];
+    const double r2 = xn * xn + yn * yn, r4 = r2 * r2, r6 = r4 * r2;
+    const double rc = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    const double xd = xn * rc + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn);
+    const double yd = yn * rc + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn);
+    r[0] = fx * xd + cx - ox;
+    r[1] = fy * yd + cy - oy;
+    if (!Jq && !Jt && !Jx) return;
+    const double rcp = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+    const double dxx = rc + 2.0 * xn * xn * rcp + 2.0 * p1 * yn + 6.0 * p2 * xn;
+    const double dxy = 2.0 * xn * yn * rcp + 2.0 * p1 * xn + 2.0 * p2 * yn;
+    const double dyy = rc + 2.0 * yn * yn * rcp + 2.0 * p2 * xn + 6.0 * p1 * yn;
+    const double iz = 1.0 / xc[2];
+    const double a11 = fx * dxx, a12 = fx * dxy, a21 = fy * dxy, a22 = fy * dyy;
+    const double D[6] = { a11 * iz, a12 * iz, -(a11 * xn + a12 * yn) * iz,  a21 * iz, a22 * iz, -(a21 * xn + a22 * yn) * iz };
+    if (Jt) memcpy(Jt, D, sizeof D);
+    if (Jx) {      /* d x / d X = R(q) * trans[:, :3] */
+        double R[9];
+        for (int i = 0; i < 9; ++i) R[i] = 2.0 * M[i] + ((i % 4 == 0) ? 1.0 : 0.0);
+        for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int i = 0; i < 3; ++i) {
+                const double rt = R[3 * i] * trans[j] + R[3 * i + 1] * trans[4 + j] + R[3 * i + 2] * trans[8 + j];
+                s += D[k * 3 + i] * rt;
+            }
+            Jx[k * 3 + j] = s;
+        }
+    }
+    if (Jq) {
+        /* d x / d u for the unit quaternion u, then through u = q / |q|: (I - u u^T) / |q| */
+        const double G[12] = {
+            2 * (-u3 * p[1] + u2 * p[2]), 2 * (u2 * p[1] + u3 * p[2]), 2 * (-2 * u2 * p[0] + u1 * p[1] + u0 * p[2]), 2 * (-2 * u3 * p[0] - u0 * p[1] + u1 * p[2]),
+            2 * (u3 * p[0] - u1 * p[2]), 2 * (u2 * p[0] - 2 * u1 * p[1] - u0 * p[2]), 2 * (u1 * p[0] + u3 * p[2]), 2 * (u0 * p[0] - 2 * u3 * p[1] + u2 * p[2]),
+            2 * (-u2 * p[0] + u1 * p[1]), 2 * (u3 * p[0] + u0 * p[1] - 2 * u1 * p[2]), 2 * (-u0 * p[0] + u3 * p[1] - 2 * u2 * p[2]), 2 * (u1 * p[0] + u2 * p[1]) };
+        const double u[4] = { u0, u1, u2, u3 };
+        double Gq[12];
+        for (int i = 0; i < 3; ++i) {
+            const double gu = G[4 * i] * u0 + G[4 * i + 1] * u1 + G[4 * i + 2] * u2 + G[4 * i + 3] * u3;
+            for (int j = 0; j < 4; ++j) Gq[4 * i + j] = (G[4 * i + j] - gu * u[j]) * sc;
+        }
+        for (int k = 0; k < 2; ++k) for (int j = 0; j < 4; ++j)
+            Jq[k * 4 + j] = D[k * 3] * Gq[j] + D[k * 3 + 1] * Gq[4 + j] + D[k * 3 + 2] * Gq[8 + j];
+    }
+}
+
+void orc_huber(double a, double s, double rho[3]) {     /* ceres::HuberLoss::Evaluate, b = a^2 */
+    const double b = a * a;
+    if (a > 0.0 && s > b) {
+        const double r = sqrt(s);
+        rho[0] = 2.0 * a * r - b;
+        rho[1] = a / r; if (rho[1] < DBL_MIN) rho[1] = DBL_MIN;
+        rho[2] = -rho[1] / (2.0 * s);
+    } else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+}
+
+double orc_toolba_cost(const orc_toolba_problem *pb, const double p[7], const double *points) {
+    double c = 0;
+    for (int v = 0; v < pb->V; ++v)
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            double r[2], rho[3];
+            orc_toolba_analytic(pb->intr, pb->trans + 12 * v, p, p + 4, points + 3 * pb->point_id[o], pb->obs_x[o], pb->obs_y[o], r, 0, 0, 0);
+            orc_huber(pb->huber, r[0] * r[0] + r[1] * r[1], rho);
+            c += rho[0];
+        }
+    return 0.5 * c;
+}
+
+void orc_toolba_normal_eq(const orc_toolba_problem *pb, const double p[7], const double *points, double *H, double *g,
+                          double *cost) {
+    const int nf = 6 + 3 * pb->P;
+    double Pq[12]; quat_plus_jac(p, Pq);
+    memset(H, 0, sizeof(double) * (size_t)nf * nf); memset(g, 0, sizeof(double) * nf);
+    double c = 0;
+    for (int v = 0; v < pb->V; ++v)
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            const int pid = pb->point_id[o];
+            double r[2], Jq[8], Jt[6], Jx[6], rho[3], J[2][9];
+            orc_toolba_analytic(pb->intr, pb->trans + 12 * v, p, p + 4, points + 3 * pid, pb->obs_x[o], pb->obs_y[o], r, Jq, Jt, Jx);
+            orc_huber(pb->huber, r[0] * r[0] + r[1] * r[1], rho);
+            c += rho[0];
+            /* ceres::Corrector with rho'' <= 0: residuals and Jacobians scaled by sqrt(rho') */
+            const double w = sqrt(rho[1]);
+            for (int k = 0; k < 2; ++k) {
+                for (int a = 0; a < 3; ++a)
+                    J[k][a] = w * (Jq[k * 4] * Pq[a] + Jq[k * 4 + 1] * Pq[3 + a] + Jq[k * 4 + 2] * Pq[6 + a] + Jq[k * 4 + 3] * Pq[9 + a]);
+                for (int a = 0; a < 3; ++a) { J[k][3 + a] = w * Jt[k * 3 + a]; J[k][6 + a] = w * Jx[k * 3 + a]; }
+            }
+            int idx[9]; for (int a = 0; a < 6; ++a) idx[a] = a; for (int a = 0; a < 3; ++a) idx[6 + a] = 6 + 3 * pid + a;
+            for (int k = 0; k < 2; ++k) {
+                const double rk = w * r[k];
+                for (int a = 0; a < 9; ++a) {
+                    g[idx[a]] += J[k][a] * rk;
+                    for (int b = 0; b < 9; ++b) H[(size_t)idx[a] * nf + idx[b]] += J[k][a] * J[k][b];
+                }
+            }
+        }
+    if (cost) *cost = 0.5 * c;
+}
+
+void orc_lm_options_toolba(orc_lm_options *o) {   /* hand_eye_registration.cpp:201-210 */
+    lm_defaults(o);
+    o->nonmonotonic = 0;
+    o->max_iterations = 100;
+    o->function_tolerance = 1e-20; o->gradient_tolerance = 1e-20; o->parameter_tolerance = 1e-20;
+}
+
+typedef struct { const orc_toolba_problem *pb; int nf; double *H, *g, *A; } tba_ctx;
+static double tba_m_linearize(void *vc, const double *x, double *diag, double *grad) {
+    tba_ctx *c = vc; double cost;
+    orc_toolba_normal_eq(c->pb, x, x + 7, c->H, c->g, &cost);
+    for (int a = 0; a < c->nf; ++a) { diag[a] = c->H[(size_t)a * c->nf + a]; grad[a] = c->g[a]; }
+    return cost;
+}
+static int tba_m_solve(void *vc, const double *D, double *delta) {
+    tba_ctx *c = vc;
+    memcpy(c->A, c->H, sizeof(double) * (size_t)c->nf * c->nf);
+    for (int a = 0; a < c->nf; ++a) { c->A[(size_t)a * c->nf + a] += D[a]; delta[a] = -c->g[a]; }
+    return orc_cholesky_solve(c->nf, c->A, delta);
+}
+static void tba_m_plus(void *vc, const double *x, const double *delta, double *xo) {
+    tba_ctx *c = vc;
+    orc_quaternion_plus(x, delta, xo);
+    for (int a = 0; a < 3; ++a) xo[4 + a] = x[4 + a] + delta[3 + a];
+    for (int a = 0; a < 3 * c->pb->P; ++a) xo[7 + a] = x[7 + a] + delta[6 + a];
+}
+static double tba_m_cost(void *vc, const double *x) { tba_ctx *c = vc; return orc_toolba_cost(c->pb, x, x + 7); }
+static double tba_m_free_norm2(void *vc, const double *x) { tba_ctx *c = vc; double s = 0; for (int i = 0; i < 7 + 3 * c->pb->P; ++i) s += x[i] * x[i]; return s; }
+
+int orc_toolba_solve(const orc_toolba_problem *pb, double p[7], double *points, const orc_lm_options *opt,
+                     orc_lm_summary *sum) {
+    const int nf = 6 + 3 * pb->P, ng = 7 + 3 * pb->P;
+    tba_ctx c = { pb, nf, malloc(sizeof(double) * (size_t)nf * nf), malloc(sizeof(double) * nf), malloc(sizeof(double) * (size_t)nf * nf) };
+    double *x = malloc(sizeof(double) * ng);
+    memcpy(x, p, 7 * sizeof(double)); memcpy(x + 7, points, sizeof(double) * 3 * pb->P);
+    lm_model m = { &c, nf, ng, tba_m_linearize, tba_m_solve, tba_m_plus, tba_m_cost, tba_m_free_norm2 };
+    const int term = (opt->strategy == 1) ? lm_nielsen(&m, x, opt, sum) : lm_ceres(&m, x, opt, sum);
+    memcpy(p, x, 7 * sizeof(double)); memcpy(points, x + 7, sizeof(double) * 3 * pb->P);
+    free(c.H); free(c.g); free(c.A); free(x);
+    return term;
+}

@@ -162,6 +162,33 @@ int orc_lm_nielsen_der(orc_lm_func func, orc_lm_func jacf, double *p, const doub
                        int m, int n, int itmax, const double opts[4], double info[10],
                        void *adata);
 
+/* ---- tool-level bundle adjustment: hand_eye_registration.cpp:48-238 / camera_ba.cpp:47-240 ---- */
+/* One global pose p = {q.w,q.x,q.y,q.z,t} (QuaternionParameterization), free board points, constant intrinsics,
+ * a fixed rigid pre-transform per view (gripper_to_base[i], row-major 3x4), HuberLoss(huber) on every 2-residual
+ * block (hand_eye_registration.cpp:168,181-188); huber <= 0: no loss function. */
+typedef struct {
+    int V, P, N;
+    const int *view_off, *point_id;
+    const double *obs_x, *obs_y;
+    const double *trans;      /* [V][12] */
+    double intr[9];           /* fx,fy,cx,cy,k1,k2,k3,p1,p2 (constants: hand_eye_registration.cpp:67-77) */
+    double huber;             /* 1.0 in the reference */
+} orc_toolba_problem;
+/* functor hand_eye_registration.cpp:60-140: r[2], Jq[2][4] (global quaternion derivative), Jt[2][3], Jx[2][3] */
+void orc_toolba_analytic(const double intr[9], const double trans[12], const double q[4], const double t[3],
+                         const double X[3], double ox, double oy, double r[2], double Jq[8], double Jt[6], double Jx[6]);
+void orc_toolba_autodiff(const double intr[9], const double trans[12], const double q[4], const double t[3],
+                         const double X[3], double ox, double oy, double r[2], double Jq[8], double Jt[6], double Jx[6]);
+/* ceres::HuberLoss::Evaluate: rho[0..2] at s = |r|^2 */
+void orc_huber(double a, double s, double rho[3]);
+double orc_toolba_cost(const orc_toolba_problem *pb, const double p[7], const double *points);   /* 1/2 sum rho(s) */
+/* robustified normal equations over the tangent space [pose 6 | points 3P]: H[(6+3P)^2], g[6+3P] */
+void orc_toolba_normal_eq(const orc_toolba_problem *pb, const double p[7], const double *points, double *H, double *g,
+                          double *cost);
+void orc_lm_options_toolba(orc_lm_options *o);   /* hand_eye_registration.cpp:201-210 */
+int orc_toolba_solve(const orc_toolba_problem *pb, double p[7], double *points, const orc_lm_options *opt,
+                     orc_lm_summary *sum);
+
 /* ---- HomographyEstimator::solveLM, homography.cpp:159-236 ------------------ */
 /* errors (homography.cpp:166-186) and jacobian (:188-207) of LMHomographyEstimator over n point pairs
  * (already gathered by the inlier list); h[8] in/out; opts as LMSolver::minimizeDer builds them

@@ -57,6 +57,12 @@ class HandEyeProblem(C.Structure):
 LM_FUNC = C.CFUNCTYPE(None, c_double_p, c_double_p, C.c_int, C.c_int, C.c_void_p)
 
 
+class ToolBAProblem(C.Structure):
+    _fields_ = [("V", C.c_int), ("P", C.c_int), ("N", C.c_int), ("view_off", c_int_p), ("point_id", c_int_p),
+                ("obs_x", c_double_p), ("obs_y", c_double_p), ("trans", c_double_p), ("intr", C.c_double * 9),
+                ("huber", C.c_double)]
+
+
 def build(force=False):
     """Compile the C restatement (and, when /root/reference exists, levmar into oracle/_ref)."""
     so = os.path.join(_HERE, "libcvx_oracle.so")
@@ -101,6 +107,15 @@ def lib():
         L.orc_lm_nielsen_der.argtypes = [LM_FUNC, LM_FUNC, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_void_p]
         L.orc_lm_nielsen_der.restype = C.c_int
         L.orc_cholesky_solve.argtypes = [C.c_int, dp, dp]; L.orc_cholesky_solve.restype = C.c_int
+        tp = C.POINTER(ToolBAProblem)
+        L.orc_toolba_analytic.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]
+        L.orc_toolba_autodiff.argtypes = L.orc_toolba_analytic.argtypes
+        L.orc_huber.argtypes = [C.c_double, C.c_double, dp]
+        L.orc_toolba_cost.argtypes = [tp, dp, dp]; L.orc_toolba_cost.restype = C.c_double
+        L.orc_toolba_normal_eq.argtypes = [tp, dp, dp, dp, dp, dp]
+        L.orc_lm_options_toolba.argtypes = [C.POINTER(LMOptions)]
+        L.orc_toolba_solve.argtypes = [tp, dp, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]
+        L.orc_toolba_solve.restype = C.c_int
         fp = C.POINTER(C.c_float)
         L.orc_homography_lm.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, dp, C.c_int, dp, dp]
         L.orc_homography_lm.restype = C.c_int
@@ -217,10 +232,45 @@ class HandEye:
         return p, s
 
 
+class ToolBA:
+    """Oracle view of the tool-level bundle adjustment (hand_eye_registration.cpp:144-238)."""
+
+    def __init__(self, view_off, point_id, obs_x, obs_y, trans, intr, n_points, huber=1.0):
+        self.view_off = i32(view_off); self.point_id = i32(point_id)
+        self.obs_x = f64(obs_x); self.obs_y = f64(obs_y); self.trans = f64(np.asarray(trans).reshape(-1, 12))
+        self.V, self.N, self.P = len(self.view_off) - 1, len(self.point_id), int(n_points)
+        self.pb = ToolBAProblem(self.V, self.P, self.N, _ip(self.view_off), _ip(self.point_id), _dp(self.obs_x),
+                                _dp(self.obs_y), _dp(self.trans), (C.c_double * 9)(*[float(v) for v in intr]), float(huber))
+        self.nf = 6 + 3 * self.P
+
+    def cost(self, p, points):
+        p, points = f64(p), f64(points)
+        return lib().orc_toolba_cost(C.byref(self.pb), _dp(p), _dp(points))
+
+    def normal_eq(self, p, points):
+        p, points = f64(p), f64(points)
+        H = np.zeros((self.nf, self.nf)); g = np.zeros(self.nf); cost = C.c_double()
+        lib().orc_toolba_normal_eq(C.byref(self.pb), _dp(p), _dp(points), _dp(H), _dp(g), C.byref(cost))
+        return H, g, cost.value
+
+    def solve(self, p, points, options):
+        p, points = f64(p).copy(), f64(points).copy(); s = LMSummary()
+        lib().orc_toolba_solve(C.byref(self.pb), _dp(p), _dp(points), C.byref(options), C.byref(s))
+        return p, points, s
+
+
+def toolba_functor(intr, trans, q, t, X, ox, oy, autodiff=False):
+    intr, trans, q, t, X = f64(intr), f64(trans), f64(q), f64(t), f64(X)
+    r = np.zeros(2); Jq = np.zeros((2, 4)); Jt = np.zeros((2, 3)); Jx = np.zeros((2, 3))
+    f = lib().orc_toolba_autodiff if autodiff else lib().orc_toolba_analytic
+    f(_dp(intr), _dp(trans), _dp(q), _dp(t), _dp(X), float(ox), float(oy), _dp(r), _dp(Jq), _dp(Jt), _dp(Jx))
+    return r, Jq, Jt, Jx
+
+
 def options(kind="refine"):
     o = LMOptions()
     {"refine": lib().orc_lm_options_refine, "handeye": lib().orc_lm_options_handeye,
-     "levmar": lib().orc_lm_options_levmar}[kind](C.byref(o))
+     "levmar": lib().orc_lm_options_levmar, "toolba": lib().orc_lm_options_toolba}[kind](C.byref(o))
     return o
 
 

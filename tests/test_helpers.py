@@ -61,3 +61,55 @@ def homography_batch(rng, sizes, **kw):
     off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.int32)
     cat = lambda k: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, np.float32)
     return off, cat(0), cat(1), cat(2), cat(3), np.stack([p[4] for p in parts])
+
+
+def _rot(axis, angle):
+    axis = np.asarray(axis, float); axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K
+
+
+def _quat_of(R):
+    w = np.sqrt(max(1e-30, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    return np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+
+
+TOOLBA_INTR = np.array([1000.0, 1005.0, 640.0, 480.0, -0.12, 0.05, 0.01, 1e-3, -1.5e-3])   # fx fy cx cy k1 k2 k3 p1 p2
+
+
+def toolba_problem(rng, V, bw=9, bh=6, tile=0.025, noise=0.3, outliers=0.03, ragged=0):
+    """Synthetic input of the tool-level bundle adjustment (hand_eye_registration.cpp:144-238): one camera pose
+    (base -> camera), V views each with a known rigid pre-transform (board -> base), board points in metres,
+    float32 pixel observations with noise and a few gross outliers for the Huber loss to act on."""
+    P = bw * bh
+    gx, gy = np.meshgrid(np.arange(bw) * tile, np.arange(bh) * tile)
+    X = np.stack([gx.ravel(), gy.ravel(), np.zeros(P)], 1).astype(np.float32).astype(np.float64)
+    Rg = _rot([1, 2, 3], 0.4); tg = np.array([0.05, -0.03, 0.12])
+    Tg = np.eye(4); Tg[:3, :3] = Rg; Tg[:3, 3] = tg                       # camera <- base
+    Tgi = np.linalg.inv(Tg)
+    fx, fy, cx, cy, k1, k2, k3, p1, p2 = TOOLBA_INTR
+    trans = np.zeros((V, 12)); view_off = [0]; pid = []; ox = []; oy = []
+    for v in range(V):
+        Tb = np.eye(4)                                                    # camera <- board
+        Tb[:3, :3] = _rot(rng.normal(size=3), rng.uniform(0, 0.6))
+        Tb[:3, 3] = [rng.uniform(-0.15, 0.15) - gx.mean(), rng.uniform(-0.1, 0.1) - gy.mean(), rng.uniform(0.5, 0.9)]
+        trans[v] = (Tgi @ Tb)[:3].reshape(-1)
+        ids = np.arange(P)
+        if ragged:
+            ids = ids[rng.uniform(size=P) > 1.0 / ragged]
+        xc = (Tb[:3, :3] @ X[ids].T).T + Tb[:3, 3]
+        xn, yn = xc[:, 0] / xc[:, 2], xc[:, 1] / xc[:, 2]
+        r2 = xn * xn + yn * yn
+        rc = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+        u = fx * (xn * rc + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)) + cx + rng.normal(0, noise, len(ids))
+        w = fy * (yn * rc + 2 * p2 * xn * yn + p1 * (r2 + 2 * yn * yn)) + cy + rng.normal(0, noise, len(ids))
+        bad = rng.uniform(size=len(ids)) < outliers
+        u = u + bad * rng.normal(0, 20, len(ids)); w = w + bad * rng.normal(0, 20, len(ids))
+        pid.append(ids); ox.append(u.astype(np.float32)); oy.append(w.astype(np.float32))
+        view_off.append(view_off[-1] + len(ids))
+    q_gt = _quat_of(Rg)
+    R0 = _rot(rng.normal(size=3), 0.02) @ Rg
+    p0 = np.concatenate([_quat_of(R0), tg + rng.normal(0, 0.01, 3)])
+    return {"V": V, "P": P, "view_off": np.array(view_off, np.int32), "point_id": np.concatenate(pid).astype(np.int32),
+            "obs_x": np.concatenate(ox).astype(np.float64), "obs_y": np.concatenate(oy).astype(np.float64),
+            "trans": trans, "intr": TOOLBA_INTR.copy(), "points": X, "p_gt": np.concatenate([q_gt, tg]), "p0": p0}
