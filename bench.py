@@ -131,6 +131,68 @@ def homography_bench(cvx_amd, torch, device, with_cpu, n=CAMERAS * VIEWS_PER_CAM
     return out
 
 
+def toolba_bench(cvx_amd, torch, device, with_cpu, V=CAMERAS * VIEWS_PER_CAMERA, bw=BOARD_W, bh=BOARD_H):
+    """bundleAdjustment of tools/hand_eye_registration.cpp at config 4's size: one camera
+    pose, V views with known pre-transforms, bw x bh free board points, Huber loss; time per LM iteration."""
+    from cvx_amd import capi
+    from cvx_amd.problem import ToolBA
+    rng = np.random.default_rng(SEED + 3)
+    P = bw * bh
+    gx, gy = np.meshgrid(np.arange(bw) * 0.025, np.arange(bh) * 0.025)
+    X = np.stack([gx.ravel(), gy.ravel(), np.zeros(P)], 1).astype(np.float32).astype(np.float64)
+
+    def rot(axis, ang):
+        axis = axis / np.linalg.norm(axis, axis=-1, keepdims=True)
+        K = np.zeros(axis.shape[:-1] + (3, 3))
+        K[..., 0, 1], K[..., 0, 2], K[..., 1, 0] = -axis[..., 2], axis[..., 1], axis[..., 2]
+        K[..., 1, 2], K[..., 2, 0], K[..., 2, 1] = -axis[..., 0], -axis[..., 1], axis[..., 0]
+        ang = np.asarray(ang)[..., None, None]
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    Rg = rot(np.array([1.0, 2.0, 3.0]), 0.4); tg = np.array([0.05, -0.03, 0.12])
+    Rb = rot(rng.normal(size=(V, 3)), rng.uniform(0, 0.6, V))
+    tb = np.stack([rng.uniform(-0.15, 0.15, V) - gx.mean(), rng.uniform(-0.1, 0.1, V) - gy.mean(), rng.uniform(0.5, 0.9, V)], 1)
+    trans = np.concatenate([Rg.T @ Rb, (Rg.T @ (tb - tg)[..., None])], axis=2).reshape(V, 12)     # base <- board
+    xc = np.einsum("vij,pj->vpi", Rb, X) + tb[:, None, :]
+    fx, fy, cx, cy, k1, k2, k3, p1, p2 = intr = np.array([1000.0, 1005.0, 640.0, 480.0, -0.12, 0.05, 0.01, 1e-3, -1.5e-3])
+    xn, yn = xc[..., 0] / xc[..., 2], xc[..., 1] / xc[..., 2]
+    r2 = xn * xn + yn * yn
+    rc = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    bad = rng.uniform(size=(V, P)) < 0.03
+    u = fx * (xn * rc + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)) + cx + rng.normal(0, 0.3, (V, P)) + bad * rng.normal(0, 20, (V, P))
+    w = fy * (yn * rc + 2 * p2 * xn * yn + p1 * (r2 + 2 * yn * yn)) + cy + rng.normal(0, 0.3, (V, P)) + bad * rng.normal(0, 20, (V, P))
+    view_off = (np.arange(V + 1) * P).astype(np.int32); pid = np.tile(np.arange(P, dtype=np.int32), V)
+    ox = u.astype(np.float32).astype(np.float64).ravel(); oy = w.astype(np.float32).astype(np.float64).ravel()
+    qw = np.sqrt(1 + np.trace(Rg)) / 2
+    q = np.array([qw, (Rg[2, 1] - Rg[1, 2]) / (4 * qw), (Rg[0, 2] - Rg[2, 0]) / (4 * qw), (Rg[1, 0] - Rg[0, 1]) / (4 * qw)])
+    p0 = np.concatenate([q + rng.normal(0, 5e-3, 4), tg + rng.normal(0, 0.01, 3)])
+    g = ToolBA(view_off, pid, ox, oy, trans, intr, P, device=device)
+    op = capi.options("toolba")
+    op.max_iterations = 10
+    g.solve(p0, X, op)
+    torch.cuda.synchronize()
+    reps = 5
+    t = time.perf_counter()
+    for _ in range(reps):
+        pp, xx, sm = g.solve(p0, X, op)
+    dt = (time.perf_counter() - t) / (reps * max(sm.iterations, 1))
+    g.close()
+    out = {"views": V, "points": P, "observations": V * P, "ms_per_lm_iteration": 1e3 * dt,
+           "observations_per_s": V * P / dt, "iterations_per_solve": sm.iterations,
+           "cost": [sm.initial_cost, sm.final_cost], "translation_error_m": float(np.max(np.abs(pp[4:] - tg)))}
+    if with_cpu:
+        from oracle import oracle as orc
+        Vs = V
+        o = orc.ToolBA(view_off[:Vs + 1], pid[:Vs * P], ox[:Vs * P], oy[:Vs * P], trans[:Vs], intr, P)
+        oo = orc.options("toolba"); oo.max_iterations = 5
+        t = time.perf_counter()
+        so = o.solve(p0, X, oo)[2]
+        dtc = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": Vs * P * so.iterations / dtc, "unit": "observations/s", "cores": 1, "kind": "port",
+                               "sample": "first %d views (%d observations), %d LM iterations, dense normal equations, %.1f s" % (
+                                   Vs, Vs * P, so.iterations, dtc)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,9 +315,10 @@ def main():
             he.close()
 
     # ---- batched homography refinement, one LM problem per view of config 4 ----
-    homography = None
+    homography = toolba = None
     if rank == 0:
         homography = homography_bench(cvx_amd, torch, local_rank, with_cpu=(world == 1 and not a.no_cpu_baseline))
+        toolba = toolba_bench(cvx_amd, torch, local_rank, with_cpu=(world == 1 and not a.no_cpu_baseline))
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -321,6 +384,7 @@ def main():
         }
         out["handeye"] = handeye
         out["homography"] = homography
+        out["tool_bundle_adjustment"] = toolba
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_views, a.cpu_iters)
         print(json.dumps(out), flush=True)

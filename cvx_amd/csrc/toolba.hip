@@ -312,11 +312,13 @@ extern "C" int cvx_toolba_create(const cvx_toolba_desc *d, cvx_toolba **out) {
                 obs[k] = d->obs_x[o]; obs[n + k] = d->obs_y[o]; view[k] = v;
             }
     }
+    // observations of one point per workgroup: whole multiples of the block, sized for >= ~1000 workgroups
+    const long long chunk = TBA_THREADS * std::max<long long>(1, std::min<long long>(TBA_CHUNK / TBA_THREADS, N / (TBA_THREADS * 1024LL)));
     std::vector<int> jp, js, jc, jfirst((size_t)P + 1, 0);
     for (int p = 0; p < P; ++p) {
         jfirst[p] = (int)jp.size();
-        for (long long s = first[p]; s < first[(size_t)p + 1]; s += TBA_CHUNK) {
-            jp.push_back(p); js.push_back((int)s); jc.push_back((int)std::min<long long>(TBA_CHUNK, first[(size_t)p + 1] - s));
+        for (long long s = first[p]; s < first[(size_t)p + 1]; s += chunk) {
+            jp.push_back(p); js.push_back((int)s); jc.push_back((int)std::min<long long>(chunk, first[(size_t)p + 1] - s));
         }
     }
     jfirst[P] = (int)jp.size();

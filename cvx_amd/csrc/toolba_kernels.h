@@ -18,7 +18,7 @@ namespace cvxt {
 
 constexpr int TBA_ACC = 64;        // 55 sums, padded to the wave width for the transposing reduction
 constexpr int TBA_THREADS = 256;
-constexpr int TBA_CHUNK = 2048;    // observations of one point per workgroup
+constexpr int TBA_CHUNK = 2048;    // most observations of one point per workgroup (the host picks a multiple of the block)
 
 struct TbaArgs {
     const double *ox, *oy;         // [N] point-major observation planes (cv::Point2f promoted to double)
@@ -95,18 +95,21 @@ __device__ __forceinline__ void tba_huber(double a, double s, double &rho0, doub
     } else { rho0 = s; rho1 = 1.0; }
 }
 
-// 64 per-lane values in, lane L returns the sum over all lanes of value L (fixed butterfly order)
-__device__ __forceinline__ double tba_transpose_reduce(double (&v)[TBA_ACC], int lane) {
+// 64 per-lane values in, lane L returns the sum over all lanes of value L (fixed butterfly order).  Template
+// recursion keeps every register index a compile-time constant (a runtime `half` sends the array to scratch).
+template <int HALF>
+__device__ __forceinline__ void tba_reduce_step(double (&v)[TBA_ACC], int lane) {
+    const bool upper = (lane & HALF) != 0;
 #pragma unroll
-    for (int half = 32; half >= 1; half >>= 1) {
-        const bool upper = (lane & half) != 0;
-#pragma unroll
-        for (int j = 0; j < half; ++j) {
-            const double send = upper ? v[j] : v[j + half];
-            const double keep = upper ? v[j + half] : v[j];
-            v[j] = keep + __shfl_xor(send, half, 64);
-        }
+    for (int j = 0; j < HALF; ++j) {
+        const double send = upper ? v[j] : v[j + HALF];
+        const double keep = upper ? v[j + HALF] : v[j];
+        v[j] = keep + __shfl_xor(send, HALF, 64);
     }
+    if constexpr (HALF > 1) tba_reduce_step<HALF / 2>(v, lane);
+}
+__device__ __forceinline__ double tba_transpose_reduce(double (&v)[TBA_ACC], int lane) {
+    tba_reduce_step<32>(v, lane);
     return v[0];
 }
 

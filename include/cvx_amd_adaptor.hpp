@@ -267,4 +267,64 @@ bool homography_solve_lm(const std::vector<Point> &pts1, const std::vector<Point
     return ok;
 }
 
+// ------------------------------------------------------------------------------------------
+// void bundleAdjustment(cam, data, gripper_to_base, pose, off, coords)
+//     tools/hand_eye_registration.cpp:144-238 (= tools/camera_ba.cpp:146-240)
+// pose: in, the initial sensor pose as the tool passes it (:431-432, 439); out, the refined pose INVERTED as :229-230
+// does.  coords: out, the refined board points (x, y, z per point, :161-166).  off: the reference only ever writes
+// zeros to it (:159, 232-234), so it is not a parameter here.  Camera goes through `Traits` like refine().
+// ------------------------------------------------------------------------------------------
+template <class Data, class Camera, class Affine, class Traits = camera_traits<Camera>>
+void bundle_adjustment(const Camera &cam, const Data &data, const std::vector<Affine> &gripper_to_base, Affine &pose,
+                       std::vector<double> &coords, int device = 0, void *stream = nullptr,
+                       cvx_lm_summary *summary = nullptr) {
+    const int V = (int)data.markers_.size(), P = (int)data.coords_.size();
+    if ((int)gripper_to_base.size() < V) throw std::invalid_argument("bundle_adjustment: one gripper pose per view needed");
+    std::vector<int> view_off(V + 1, 0), point_id;
+    std::vector<double> ox, oy, trans(12 * (size_t)(V > 0 ? V : 1));
+    for (int v = 0; v < V; ++v) {
+        for (const auto &m : data.markers_[v]) {                 // :171-191
+            point_id.push_back(m.id_); ox.push_back((double)m.pt_.x); oy.push_back((double)m.pt_.y);
+        }
+        view_off[v + 1] = (int)point_id.size();
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) trans[12 * (size_t)v + 4 * r + c] = gripper_to_base[v].matrix()(r, c);
+    }
+    coords.clear();
+    for (int i = 0; i < P; ++i) {
+        coords.push_back(data.coords_[i].x); coords.push_back(data.coords_[i].y); coords.push_back(data.coords_[i].z);
+    }
+    double M[16], q[4], t[3];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) M[4 * c + r] = pose.matrix()(r, c);
+    cvx_affine_to_quat_trans(M, q, t);                           // Quaterniond q(pose.rotation()), :153-158
+    double p[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
+    cvx_toolba_desc d;
+    d.n_views = V; d.n_points = P; d.n_obs = (int64_t)point_id.size();
+    d.view_off = view_off.data(); d.point_id = point_id.data(); d.obs_x = ox.data(); d.obs_y = oy.data();
+    d.trans = trans.data();
+    Traits::get(cam, d.intrinsics);                              // fx fy cx cy k1 k2 k3 p1 p2 from :67-77
+    d.huber = 1.0;                                               // :168
+    d.device = device; d.stream = stream;
+    cvx_toolba *h = nullptr;
+    check(cvx_toolba_create(&d, &h), "cvx_toolba_create");
+    struct Guard { cvx_toolba *h; ~Guard() { cvx_toolba_destroy(h); } } guard{h};
+    cvx_lm_options opt;
+    cvx_lm_options_toolba(&opt);
+    cvx_lm_summary local;
+    check(cvx_toolba_solve(h, p, coords.data(), &opt, summary ? summary : &local), "cvx_toolba_solve");
+    cvx_quat_trans_to_affine(p, M);                              // Translation(tr) * qx.toRotationMatrix(), :225-229
+    // pose = pose.inverse() (:230): general affine inverse, since q is not renormalised
+    const double a = M[0], b = M[4], c = M[8], e = M[1], f = M[5], g = M[9], k = M[2], l = M[6], m = M[10];
+    const double det = a * (f * m - g * l) - b * (e * m - g * k) + c * (e * l - f * k);
+    const double I[9] = {(f * m - g * l) / det, (c * l - b * m) / det, (b * g - c * f) / det,
+                         (g * k - e * m) / det, (a * m - c * k) / det, (c * e - a * g) / det,
+                         (e * l - f * k) / det, (b * k - a * l) / det, (a * f - b * e) / det};
+    for (int r = 0; r < 3; ++r) {
+        for (int cc = 0; cc < 3; ++cc) pose.matrix()(r, cc) = I[3 * r + cc];
+        pose.matrix()(r, 3) = -(I[3 * r] * M[12] + I[3 * r + 1] * M[13] + I[3 * r + 2] * M[14]);
+    }
+    pose.matrix()(3, 0) = 0; pose.matrix()(3, 1) = 0; pose.matrix()(3, 2) = 0; pose.matrix()(3, 3) = 1;
+}
+
 }  // namespace cvx_amd

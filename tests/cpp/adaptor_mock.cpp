@@ -123,6 +123,59 @@ int main() {
     }
     std::printf("], \"hom_ok\": %d, \"hom\": [", ok ? 1 : 0);
     for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", H.m[i]);
-    std::printf("]}\n");
+    std::printf("], ");
+
+    // bundleAdjustment of tools/hand_eye_registration.cpp on the same detections: the "gripper" transforms are
+    // chosen so that pose * trans_v equals each view's ground-truth board pose; start = a perturbed pose, inverted
+    // on entry like the tool does (:431-432)
+    std::vector<Mat4> g2b(V);
+    const double wg[3] = {0.1, -0.2, 0.15};
+    double Rg[9];
+    cvx_angle_axis_to_rotation(wg, Rg);                       // column-major
+    const double tgv[3] = {10.0, -20.0, 30.0};
+    for (int v = 0; v < V; ++v) {
+        double Rv[9];
+        cvx_angle_axis_to_rotation(&pg[6 * v], Rv);
+        Mat4 &M = g2b[v];
+        for (int i = 0; i < 16; ++i) M.m[i] = 0;
+        // trans_v = Tg^-1 * Tv:  R = Rg^T Rv, t = Rg^T (tv - tg)
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += Rg[3 * r + k] * Rv[3 * c + k];     // Rg^T(r,k) = Rg_colmajor[3 r + k]
+                M(r, c) = s;
+            }
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += Rg[3 * r + k] * (pg[6 * v + 3 + k] - tgv[k]);
+            M(r, 3) = s;
+        }
+        M(3, 3) = 1;
+    }
+    Mat4 bpose;                                               // start: rotation slightly off, translation off
+    {
+        const double w0[3] = {0.11, -0.19, 0.16};
+        double R0[9];
+        cvx_angle_axis_to_rotation(w0, R0);
+        for (int i = 0; i < 16; ++i) bpose.m[i] = 0;
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) bpose(r, c) = R0[3 * c + r];
+        bpose(0, 3) = 11.0; bpose(1, 3) = -19.0; bpose(2, 3) = 31.0; bpose(3, 3) = 1;
+    }
+    std::printf("\"ba_start\": [");
+    for (int i = 0; i < 16; ++i) std::printf("%s%.17g", i ? ", " : "", bpose.m[i]);
+    Camera cam_gt = {ig[0], ig[1], ig[2], ig[3], {ig[4], ig[5], ig[7], ig[8], ig[6]}};
+    Data data_gt = data;
+    for (int p = 0; p < P; ++p) data_gt.coords_[p] = {(float)xg[3 * p], (float)xg[3 * p + 1], (float)xg[3 * p + 2]};
+    std::vector<double> coords;
+    cvx_lm_summary bsum;
+    try {
+        cvx_amd::bundle_adjustment(cam_gt, data_gt, g2b, bpose, coords, 0, nullptr, &bsum);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 7;
+    }
+    std::printf("], \"ba_pose_inv\": [");
+    for (int i = 0; i < 16; ++i) std::printf("%s%.17g", i ? ", " : "", bpose.m[i]);
+    std::printf("], \"ba_cost\": [%.17g, %.17g], \"ba_iterations\": %d, \"ba_coords0\": [%.17g, %.17g, %.17g]}\n",
+                bsum.initial_cost, bsum.final_cost, bsum.iterations, coords[0], coords[1], coords[2]);
     return 0;
 }

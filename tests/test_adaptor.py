@@ -71,3 +71,27 @@ def test_adaptor_refine_and_handeye_match_oracle(orc):
     r, h, info = orc.homography_lm(x1, y1, x2, y2, out["hom_start"])
     assert out["hom_ok"] == 1 and r > 0
     assert out["hom"][:8] == h.tolist() and out["hom"][8] == 1.0
+    # tool-level bundle adjustment: same problem rebuilt here and solved by the oracle
+    from oracle import oracle as orc_mod
+    wg = np.array([0.1, -0.2, 0.15]); tg = np.array([10.0, -20.0, 30.0])
+    Rg = np.zeros(9); L.cvx_angle_axis_to_rotation(cvx_amd.capi.pd(wg), cvx_amd.capi.pd(Rg)); Rg = Rg.reshape(3, 3).T
+    trans = np.zeros((d["V"], 12))
+    for v in range(d["V"]):
+        Rv = np.zeros(9); L.cvx_angle_axis_to_rotation(cvx_amd.capi.pd(d["poses_gt"][v, :3].copy()), cvx_amd.capi.pd(Rv))
+        Rv = Rv.reshape(3, 3).T
+        trans[v] = np.concatenate([Rg.T @ Rv, (Rg.T @ (d["poses_gt"][v, 3:] - tg))[:, None]], axis=1).reshape(-1)
+    start = np.array(out["ba_start"]); q0 = np.zeros(4); t0 = np.zeros(3)
+    L.cvx_affine_to_quat_trans(cvx_amd.capi.pd(start.copy()), cvx_amd.capi.pd(q0), cvx_amd.capi.pd(t0))
+    ob = orc_mod.ToolBA(d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], trans, d["intr_gt"][0], 54)
+    pts_gt = d["points_gt"].astype(np.float32).astype(np.float64)
+    pb, xb, sb = ob.solve(np.concatenate([q0, t0]), pts_gt, orc.options("toolba"))
+    assert abs(out["ba_cost"][0] - sb.initial_cost) <= 1e-9 * sb.initial_cost
+    assert abs(out["ba_cost"][1] - sb.final_cost) <= 1e-9 * sb.final_cost
+    Mo = np.zeros(16); L.cvx_quat_trans_to_affine(cvx_amd.capi.pd(pb.copy()), cvx_amd.capi.pd(Mo))
+    inv = np.linalg.inv(Mo.reshape(4, 4).T)                         # the tool returns the inverted pose (:229-230)
+    got = np.array(out["ba_pose_inv"]).reshape(4, 4).T
+    assert np.max(np.abs(got - inv)) <= 1e-7 * np.max(np.abs(inv))
+    assert np.max(np.abs(np.array(out["ba_coords0"]) - xb[0])) <= 1e-7
+    # and it lands on the generating pose: pose^-1 = (Rg, tg)^-1
+    Tg = np.eye(4); Tg[:3, :3] = Rg; Tg[:3, 3] = tg
+    assert np.max(np.abs(got - np.linalg.inv(Tg))) < 0.05
