@@ -352,7 +352,12 @@ private:
             f.intr = h->d_intr[h->cur]; f.points = h->d_points[h->cur];
             f.intr_cand = h->d_intr[nxt]; f.points_cand = h->d_points[nxt];
             f.ds_emb = h->d_ds_emb; f.delta_s = h->d_delta_s; f.R = h->d_E2;
-            hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(256), h->fin_lds, h->stream, f);
+            if (ns <= cvxs::FIN_UPD + cvxs::TB) {
+                CVX_HIP(hipFuncSetAttribute((const void *)cvxs::k_solve_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fin_lds));
+                hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(cvxs::FIN_THREADS), h->fin_lds, h->stream, f);
+            } else {
+                hipLaunchKernelGGL(cvxs::k_solve_finish_wide, dim3(1), dim3(256), h->fin_lds, h->stream, f);
+            }
             CVX_HIP(hipGetLastError());
         }
         ph_end(h, PH_SOLVE);
@@ -589,7 +594,8 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_HIP(hipMemsetAsync(h->d_Ds, 0, (size_t)std::max(1, h->ns) * sizeof(double), s));
     CVX_TRY(dev_alloc(&h->d_delta_s, (size_t)std::max(1, h->ns)));
     CVX_TRY(dev_alloc(&h->d_fail, 1));
-    h->fin_lds = sizeof(double) * ((size_t)h->npad + cvxs::TB * (cvxs::TB + 1) + 8 * cvxs::TB + 256);
+    h->fin_lds = sizeof(double) * (h->ns <= cvxs::FIN_UPD + cvxs::TB ? cvxs::finish_lds_doubles(h->npad)
+                                                                      : (size_t)h->npad + cvxs::TB * (cvxs::TB + 1) + 8 * cvxs::TB + 256);
 #undef CVX_TRY
     h->s2_shared.assign((size_t)std::max(1, h->ns), 1.0);
     CVX_HIP(hipMemcpyAsync(h->d_s2sh, h->s2_shared.data(), sizeof(double) * std::max(1, h->ns), hipMemcpyHostToDevice, s));

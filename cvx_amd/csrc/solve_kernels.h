@@ -229,7 +229,200 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_solve_finish(FinishArgs a) {
+// the step and its scalars (shared tail of both finish kernels); NT = threads of the workgroup
+template <int NT>
+__device__ __forceinline__ void finish_tail(const FinishArgs &a, const double *xs, double *red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    const double *gs = a.E + (size_t)n * n + n, *dU = gs + n;
+    double ms = 0.0, ss2 = 0.0, gm = 0.0, dm = 0.0, bad = (double)(*a.fail != 0);
+    for (int i = tid; i < n; i += NT) {
+        const double ds = xs[i];
+        a.delta_s[i] = ds;
+        if (!(fabs(ds) < 1.7e308)) bad = 1.0;
+        ms += ds * (a.Ds[i] * ds - gs[i]);
+        ss2 += ds * ds;
+        gm = fmax(gm, fabs(gs[i]));
+        dm = fmax(dm, dU[i]);
+    }
+    const int ncam = a.C * a.ncf;
+    double xs2 = 0.0, fs2 = 0.0;
+    for (int idx = tid; idx < 9 * a.C; idx += NT) {
+        const int c = idx / 9, kk = idx % 9;
+        double v = a.intr[idx];
+        if (a.cam_free) {
+            xs2 += v * v;
+            if (!(a.fix_k3 && kk == 6)) {
+                fs2 += v * v;
+                const int kf = (a.fix_k3 && kk > 6) ? kk - 1 : kk;
+                v += xs[c * a.ncf + kf];
+            }
+        }
+        a.intr_cand[idx] = v;
+    }
+    for (int q = tid; q < 3 * a.P; q += NT) {
+        double v = a.points[q];
+        if (a.pts_free) { xs2 += v * v; fs2 += v * v; v += xs[ncam + q]; }
+        a.points_cand[q] = v;
+    }
+    for (int e = tid; e < a.C * a.ZC; e += NT) {
+        const int c = e / a.ZC, col = e % a.ZC;
+        double v = 0.0;
+        if (a.pts_free && col < 3 * a.P) v = xs[ncam + col];
+        else if (a.cam_free && col >= a.camcol0 && col < a.camcol0 + 9) {
+            const int kk = col - a.camcol0;
+            if (!(a.fix_k3 && kk == 6)) v = xs[c * a.ncf + ((a.fix_k3 && kk > 6) ? kk - 1 : kk)];
+        } else if (col == a.ycol) v = 1.0;
+        a.ds_emb[e] = v;
+    }
+    ms = wave_sum(ms); ss2 = wave_sum(ss2); xs2 = wave_sum(xs2); fs2 = wave_sum(fs2);
+    gm = wave_max(gm); dm = wave_max(dm); bad = wave_max(bad);
+    if (lane == 0) {
+        double *rw = red + 8 * wave;
+        rw[0] = ms; rw[1] = ss2; rw[2] = xs2; rw[3] = fs2; rw[4] = gm; rw[5] = dm; rw[6] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ms = 0.0; ss2 = 0.0; xs2 = 0.0; fs2 = 0.0; gm = 0.0; dm = 0.0; bad = 0.0;
+        for (int wv = 0; wv < NT / 64; ++wv) {
+            const double *rw = red + 8 * wv;
+            ms += rw[0]; ss2 += rw[1]; xs2 += rw[2]; fs2 += rw[3];
+            gm = fmax(gm, rw[4]); dm = fmax(dm, rw[5]); bad = fmax(bad, rw[6]);
+        }
+    }
+    if (tid == 0) {
+        const double *scal = a.E + a.E_scal;
+        double gp = 0.0, dp = 0.0;
+        for (int q = 0; q < a.nranks; ++q) { gp = fmax(gp, scal[2 + q]); dp = fmax(dp, scal[2 + a.nranks + q]); }
+        a.R[4] = ms; a.R[5] = ss2; a.R[6] = xs2; a.R[7] = fs2; a.R[8] = bad; a.R[9] = gm; a.R[10] = dm;
+        a.R[11] = scal[0]; a.R[12] = scal[1]; a.R[13] = gp; a.R[14] = dp; a.R[15] = 0.0;
+    }
+}
+
+constexpr int FIN_THREADS = 512;                 // wave 0 solves, waves 1-7 stream L and apply it
+constexpr int FIN_UPD = FIN_THREADS - 64;        // one updater thread per column: n <= FIN_UPD + 32
+constexpr int FIN_TILE = TB * (TB + 1);
+__host__ __device__ inline size_t finish_lds_doubles(int npad) { return (size_t)npad + 6 * FIN_TILE + 64; }
+
+// Back substitution L^T x = y (y = row n of L, left there by the forward elimination) and the step's scalars, one
+// workgroup.  Tile row T of L (rows 32T.., columns 0..32T+31) is used three ways, all fetched ahead of need:
+//   * its diagonal tile and the tile left of it go through LDS (three rotating buffers, loaded two steps early)
+//     to wave 0, which solves the 32 unknowns of tile T and applies them to the NEXT tile's right-hand side --
+//     the only work on the critical path;
+//   * every other column belongs to one updater thread, which loads its 32 entries of tile row T while tile T is
+//     being solved and applies them one step later, while wave 0 is already solving tile T-1.
+__global__ void __launch_bounds__(FIN_THREADS) k_solve_finish(FinishArgs a) {
+    extern __shared__ double sm[];
+    double *xs = sm;                       // [npad]
+    double *bufs = xs + a.npad;            // 3 x { diag tile [32][33], left tile [32][33] }
+    double *red = bufs + 6 * FIN_TILE;     // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n, ld = a.ld;
+    for (int i = tid; i < a.npad; i += FIN_THREADS) xs[i] = (i < n) ? a.L[(size_t)n * ld + i] : 0.0;
+#ifdef CVX_STAMPS
+    int sti = 0;
+#define STAMP() do { if (tid == 0) a.stamps[sti++] = wall_clock64(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+    STAMP();
+    const int nTn = (n + TB - 1) / TB;
+    const int u = tid - 64;                // updater index = column it owns
+    // element e (0..2047) of the two LDS tiles of tile row T: e < 1024 diagonal tile, else the tile left of it
+    auto tile_src = [&](int T, int e) -> double {
+        const int half = e >> 10, r = (e >> 5) & 31, c = e & 31;
+        const int col = (T - half) * TB + c;
+        return (T >= 0 && col >= 0) ? a.L[(size_t)(T * TB + r) * ld + col] : 0.0;
+    };
+    auto tile_dst = [&](int T, int e) -> double * {
+        const int half = e >> 10, r = (e >> 5) & 31, c = e & 31;
+        return bufs + (size_t)(((T % 3) + 3) % 3) * 2 * FIN_TILE + half * FIN_TILE + r * (TB + 1) + c;
+    };
+    double hold[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old[TB], cur[TB];
+#pragma unroll
+    for (int c = 0; c < TB; ++c) { old[c] = 0.0; cur[c] = 0.0; }
+    if (wave > 0) {
+        // prologue: the last tile row's LDS tiles directly, the one above it into `hold`
+        for (int e = u; e < 2048; e += FIN_UPD) *tile_dst(nTn - 1, e) = tile_src(nTn - 1, e);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int e = u + FIN_UPD * q; if (e < 2048) hold[q] = tile_src(nTn - 2, e); }
+    }
+    __syncthreads();
+    // one step; `use` = this thread's column of tile row kt+1 (fetched a step ago), `get` receives tile row kt.
+    // The barrier waits for LDS traffic only: the global loads into `get` and `hold` stay in flight across it.
+    auto step = [&](int kt, double (&use)[TB], double (&get)[TB]) {
+        if (wave == 0) {
+            const double *tile = bufs + (size_t)(kt % 3) * 2 * FIN_TILE;
+            const int m = lane & 31;
+            const double invm = 1.0 / tile[m * (TB + 1) + m];
+            double rhs = xs[kt * TB + m] * invm;        // lane m carries rhs_m / L_mm
+            // w[c] = L[c][m] / L_mm: x_c = rhs(lane c) once every c' > c has been eliminated
+            double w[TB];
+#pragma unroll
+            for (int c = 0; c < TB; ++c) w[c] = tile[c * (TB + 1) + m] * invm;
+#pragma unroll
+            for (int c = TB - 1; c > 0; --c) {
+                const double xc = readlane_f64(rhs, c);
+                if (m < c) rhs = fma(-w[c], xc, rhs);
+            }
+            if (lane < 32) xs[kt * TB + m] = rhs;
+        } else {
+            // (1) LDS tiles of tile row kt-1 (loaded during the previous step), then start fetching those of kt-2
+            if (kt >= 1) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) { const int e = u + FIN_UPD * q; if (e < 2048) *tile_dst(kt - 1, e) = hold[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { const int e = u + FIN_UPD * q; if (e < 2048) hold[q] = tile_src(kt - 2, e); }
+            // (2) this thread's column of tile row kt, for the next step (columns left of tile kt-1 only)
+            if (u < (kt - 1) * TB) {
+                const double *Lc = a.L + (size_t)(kt * TB) * ld + u;
+#pragma unroll
+                for (int c = 0; c < TB; ++c) get[c] = Lc[(size_t)c * ld];
+            }
+            // (3) apply tile row kt+1 now that x of tile kt+1 is known
+            if (kt + 1 < nTn && u < kt * TB) {
+                const double *xk = xs + (kt + 1) * TB;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < TB; c += 4) {
+                    s0 += use[c] * xk[c];
+                    s1 += use[c + 1] * xk[c + 1];
+                    s2 += use[c + 2] * xk[c + 2];
+                    s3 += use[c + 3] * xk[c + 3];
+                }
+                xs[u] -= (s0 + s1) + (s2 + s3);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        STAMP();
+        if (wave == 0 && kt >= 1) {
+            // right-hand side of tile kt-1: remove the unknowns just found (lanes 32-63 take the upper 16 of them)
+            const double *left = bufs + (size_t)(kt % 3) * 2 * FIN_TILE + FIN_TILE;
+            const int m = lane & 31, c0 = (lane >> 5) * 16;
+            const double *xk = xs + kt * TB;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c += 2) {
+                s0 += left[(c0 + c) * (TB + 1) + m] * xk[c0 + c];
+                s1 += left[(c0 + c + 1) * (TB + 1) + m] * xk[c0 + c + 1];
+            }
+            double sacc = s0 + s1;
+            sacc += __shfl_xor(sacc, 32, 64);
+            if (lane < 32) xs[(kt - 1) * TB + m] -= sacc;
+        }
+    };
+    for (int kt = nTn - 1; kt >= 0; kt -= 2) {
+        step(kt, old, cur);
+        if (kt >= 1) step(kt - 1, cur, old);
+    }
+    __syncthreads();
+    STAMP();
+    finish_tail<FIN_THREADS>(a, xs, red);
+}
+
+// general form for reduced systems wider than FIN_UPD + 32 unknowns: one tile at a time, no look-ahead
+__global__ void __launch_bounds__(256) k_solve_finish_wide(FinishArgs a) {
     extern __shared__ double sm[];
     double *xs = sm;                       // [npad]
     double *tile = xs + a.npad;            // [32][33]
@@ -307,71 +500,7 @@ __global__ void __launch_bounds__(256) k_solve_finish(FinishArgs a) {
         __syncthreads();
         STAMP();
     }
-    // ---- the step and its scalars ----
-    const double *gs = a.E + (size_t)n * n + n, *dU = gs + n;
-    double ms = 0.0, ss2 = 0.0, gm = 0.0, dm = 0.0, bad = (double)(*a.fail != 0);
-    for (int i = tid; i < n; i += 256) {
-        const double ds = xs[i];
-        a.delta_s[i] = ds;
-        if (!(fabs(ds) < 1.7e308)) bad = 1.0;
-        ms += ds * (a.Ds[i] * ds - gs[i]);
-        ss2 += ds * ds;
-        gm = fmax(gm, fabs(gs[i]));
-        dm = fmax(dm, dU[i]);
-    }
-    const int ncam = a.C * a.ncf;
-    double xs2 = 0.0, fs2 = 0.0;
-    for (int idx = tid; idx < 9 * a.C; idx += 256) {
-        const int c = idx / 9, kk = idx % 9;
-        double v = a.intr[idx];
-        if (a.cam_free) {
-            xs2 += v * v;
-            if (!(a.fix_k3 && kk == 6)) {
-                fs2 += v * v;
-                const int kf = (a.fix_k3 && kk > 6) ? kk - 1 : kk;
-                v += xs[c * a.ncf + kf];
-            }
-        }
-        a.intr_cand[idx] = v;
-    }
-    for (int q = tid; q < 3 * a.P; q += 256) {
-        double v = a.points[q];
-        if (a.pts_free) { xs2 += v * v; fs2 += v * v; v += xs[ncam + q]; }
-        a.points_cand[q] = v;
-    }
-    for (int e = tid; e < a.C * a.ZC; e += 256) {
-        const int c = e / a.ZC, col = e % a.ZC;
-        double v = 0.0;
-        if (a.pts_free && col < 3 * a.P) v = xs[ncam + col];
-        else if (a.cam_free && col >= a.camcol0 && col < a.camcol0 + 9) {
-            const int kk = col - a.camcol0;
-            if (!(a.fix_k3 && kk == 6)) v = xs[c * a.ncf + ((a.fix_k3 && kk > 6) ? kk - 1 : kk)];
-        } else if (col == a.ycol) v = 1.0;
-        a.ds_emb[e] = v;
-    }
-    ms = wave_sum(ms); ss2 = wave_sum(ss2); xs2 = wave_sum(xs2); fs2 = wave_sum(fs2);
-    gm = wave_max(gm); dm = wave_max(dm); bad = wave_max(bad);
-    if (lane == 0) {
-        double *rw = red + 8 * wave;
-        rw[0] = ms; rw[1] = ss2; rw[2] = xs2; rw[3] = fs2; rw[4] = gm; rw[5] = dm; rw[6] = bad;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        ms = (red[0] + red[8]) + (red[16] + red[24]);
-        ss2 = (red[1] + red[9]) + (red[17] + red[25]);
-        xs2 = (red[2] + red[10]) + (red[18] + red[26]);
-        fs2 = (red[3] + red[11]) + (red[19] + red[27]);
-        gm = fmax(fmax(red[4], red[12]), fmax(red[20], red[28]));
-        dm = fmax(fmax(red[5], red[13]), fmax(red[21], red[29]));
-        bad = fmax(fmax(red[6], red[14]), fmax(red[22], red[30]));
-    }
-    if (tid == 0) {
-        const double *scal = a.E + a.E_scal;
-        double gp = 0.0, dp = 0.0;
-        for (int q = 0; q < a.nranks; ++q) { gp = fmax(gp, scal[2 + q]); dp = fmax(dp, scal[2 + a.nranks + q]); }
-        a.R[4] = ms; a.R[5] = ss2; a.R[6] = xs2; a.R[7] = fs2; a.R[8] = bad; a.R[9] = gm; a.R[10] = dm;
-        a.R[11] = scal[0]; a.R[12] = scal[1]; a.R[13] = gp; a.R[14] = dp; a.R[15] = 0.0;
-    }
+    finish_tail<256>(a, xs, red);
 }
 
 }  // namespace cvxs

@@ -41,7 +41,9 @@ int main(int argc, char **argv) {
 #ifdef CVX_STAMPS
     long long *dst; CK(hipMalloc(&dst, 8 * 256)); CK(hipMemset(dst, 0, 8 * 256)); f.stamps = dst;
 #endif
-    const size_t lds = 8 * ((size_t)npad + 32 * 33 + 8 * 32 + 256);
+    const bool wide = n > cvxs::FIN_UPD + cvxs::TB;
+    const size_t lds = wide ? 8 * ((size_t)npad + 32 * 33 + 8 * 32 + 256) : 8 * cvxs::finish_lds_doubles(npad);
+    if (!wide) CK(hipFuncSetAttribute((const void *)cvxs::k_solve_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     float t_d = 0, t_c = 0, t_f = 0;
     const int reps = 20;
     for (int rep = 0; rep < reps + 2; ++rep) {
@@ -54,7 +56,8 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(cvxs::k_chol_step, dim3(blocks), dim3(256), 0, 0, dA, dL, npad, n, k, nT, dfail);
         }
         CK(hipEventRecord(ev[2]));
-        hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(256), lds, 0, f);
+        if (wide) hipLaunchKernelGGL(cvxs::k_solve_finish_wide, dim3(1), dim3(256), lds, 0, f);
+        else hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(cvxs::FIN_THREADS), lds, 0, f);
         CK(hipEventRecord(ev[3]));
         CK(hipDeviceSynchronize());
         float a, b, c;
