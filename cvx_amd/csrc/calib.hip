@@ -182,6 +182,18 @@ int launch_pose_prepare(cvx_calib *h, int which) {
 // Enqueue one linearisation at the current point: pose tables, normal-equation blocks, Schur
 // contraction, fixed-order slab sums, assembly of E, and the exchange step.  Nothing is copied to
 // the host (a host-buffer exchange hook is the exception: E makes the round trip the hook asks for).
+// K3: slab[chunk] = Z_chunk^T Z_chunk over the 16x16 blocks of the upper triangle (reads Z, writes the slab only)
+int launch_schur(cvx_calib *h) {
+    K3Args k;
+    k.Z = h->d_Z; k.chk_row0 = h->d_chk_row0; k.slab = h->d_slab_tile;
+    k.ZC = h->ZC; k.ZCp = h->ZCp; k.KB = h->KB; k.n_chunks = h->n_chunks; k.nb = h->nb; k.nblk = h->nblk; k.parts = h->parts;
+    const int blocks = 8 * ((h->n_chunks + 7) / 8) * h->parts;
+    CVX_HIP(hipFuncSetAttribute((const void *)k_schur_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    hipLaunchKernelGGL(k_schur_syrk, dim3(blocks), dim3(64 * K3_WAVES), h->k3_lds, h->stream, k);
+    CVX_HIP(hipGetLastError());
+    return CVX_OK;
+}
+
 int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_scale) {
     int st = launch_pose_prepare(h, h->cur);
     if (st) return st;
@@ -197,14 +209,9 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
     ph_end(h, PH_NORMAL);
     const bool schur = !init_mode && h->ns > 0;
     if (schur) {
-        K3Args k;
-        k.Z = h->d_Z; k.chk_row0 = h->d_chk_row0; k.slab = h->d_slab_tile;
-        k.ZC = h->ZC; k.ZCp = h->ZCp; k.KB = h->KB; k.n_chunks = h->n_chunks; k.nb = h->nb; k.nblk = h->nblk; k.parts = h->parts;
-        const int blocks = 8 * ((h->n_chunks + 7) / 8) * h->parts;
-        CVX_HIP(hipFuncSetAttribute((const void *)k_schur_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
         ph_begin(h, PH_SCHUR);
-        hipLaunchKernelGGL(k_schur_syrk, dim3(blocks), dim3(64 * K3_WAVES), h->k3_lds, h->stream, k);
-        CVX_HIP(hipGetLastError());
+        st = launch_schur(h);
+        if (st) return st;
         ph_end(h, PH_SCHUR);
     }
     ph_begin(h, PH_ASSEMBLE);
@@ -726,6 +733,30 @@ extern "C" int cvx_calib_linear_step(cvx_calib *h, const cvx_damping *d, double 
     if (!s.ok) return CVX_ERR_NUMERIC;
     if (cand_cost) *cand_cost = s.cand_cost;
     if (model_change) *model_change = s.model_change;
+    return CVX_OK;
+}
+
+extern "C" int cvx_calib_time_schur(cvx_calib *h, int reps, double *ms_per_launch) {
+    if (!h || reps < 1 || !ms_per_launch) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    *ms_per_launch = 0.0;
+    if (h->ns <= 0 || h->V <= 0) return CVX_OK;
+    const cvx_damping d = {1e-4, 0.0, 1e-6, 1e32};
+    int st = linearize(h, d, false, false);         // makes Z current
+    if (st) return st;
+    hipEvent_t e0, e1;
+    CVX_HIP(hipEventCreate(&e0));
+    CVX_HIP(hipEventCreate(&e1));
+    st = launch_schur(h);                            // one untimed launch
+    CVX_HIP(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps && !st; ++i) st = launch_schur(h);
+    CVX_HIP(hipEventRecord(e1, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    CVX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (st) return st;
+    *ms_per_launch = (double)ms / reps;
     return CVX_OK;
 }
 

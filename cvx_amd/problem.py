@@ -98,6 +98,11 @@ class Calib:
         names = ["normal_eq", "schur", "assemble", "backsubst", "cost", "solve"]
         return {n: (ms[i], int(ms[8 + i])) for i, n in enumerate(names)}
 
+    def time_schur(self, reps=20):
+        ms = C.c_double()
+        check(lib().cvx_calib_time_schur(self.h, int(reps), C.byref(ms)), "cvx_calib_time_schur")
+        return ms.value
+
     def geometry(self):
         g = (C.c_int64 * 8)()
         check(lib().cvx_calib_geometry(self.h, g), "geometry")

@@ -187,6 +187,10 @@ double cvx_calib_refine_return(double total_cost, int64_t n_obs_total);
  * (damp, tiled Cholesky, finish); ms[8..15]: launches counted per phase.  cvx_calib_enable_timing resets the accumulators. */
 int cvx_calib_enable_timing(cvx_calib *h, int enable);
 int cvx_calib_phase_times(cvx_calib *h, double ms[16]);
+/* average duration (ms) of the Schur-contraction kernel k_schur_syrk over `reps` back-to-back launches on the
+ * handle's stream at the current parameters, bracketed by two hipEvents: the per-launch figure bench.py's
+ * `roofline` uses (per-phase events in a running iteration add stream bubbles of their own) */
+int cvx_calib_time_schur(cvx_calib *h, int reps, double *ms_per_launch);
 
 /* launch geometry, for stating algorithmic work: [0] Z columns, [1] reduced-system size,
  * [2] normal-equation workgroups, [3] Schur row chunks, [4] 16x16 blocks of the upper triangle of Z^T Z,
