@@ -71,7 +71,8 @@ struct cvx_calib {
     double *d_E = nullptr, *h_E = nullptr;
     size_t E_count = 0, E_scal = 0;
     double *d_ds_emb = nullptr, *h_ds_emb = nullptr, *d_dposes = nullptr, *d_out_view = nullptr;
-    double *d_cost_partial = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
+    double *d_cost_partial = nullptr, *d_cost_view = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
+    hipEvent_t ev_step = nullptr;
     double *d_eval = nullptr;
     // device: damped reduced solve (solve_kernels.h)
     int npad = 32, nT = 1;
@@ -99,7 +100,7 @@ cvx_calib::~cvx_calib() {
     void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
-                    d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial,
+                    d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
                     d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -108,6 +109,7 @@ cvx_calib::~cvx_calib() {
     if (h_E2) (void)hipHostFree(h_E2);
     if (ev_made)
         for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
+    if (ev_step) (void)hipEventDestroy(ev_step);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -370,29 +372,30 @@ private:
         ph_end(h, PH_SOLVE);
         ph_begin(h, PH_BACKSUBST);
         if (h->V > 0) {
-            hipLaunchKernelGGL(k_backsubst, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, h->d_Z, h->d_Linv, h->d_Dv,
+            // pose steps, candidate poses and the candidate's cost per view in one pass
+            hipLaunchKernelGGL(k_backsubst_cost, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, h->d_Z, h->d_Linv, h->d_Dv,
                                h->d_gv, h->d_ds_emb, h->d_cam_of_view, h->d_poses[h->cur], h->d_poses[nxt],
-                               keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V, h->ZC);
+                               keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V, h->ZC,
+                               h->d_view_off, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[nxt], h->d_points[nxt],
+                               h->d_cost_view);
             CVX_HIP(hipGetLastError());
         }
         ph_end(h, PH_BACKSUBST);
-        h->rt_valid[nxt] = false;
-        st = launch_pose_prepare(h, nxt);
-        if (st) return st;
         ph_begin(h, PH_COST);
-        hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
-                           h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[nxt], h->d_points[nxt], h->d_rt[nxt],
-                           (long long)h->N, h->d_cost_partial);
-        CVX_HIP(hipGetLastError());
-        ph_end(h, PH_COST);
-        hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
+        hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V,
                            h->d_out_view, h->V, h->d_E2);
         CVX_HIP(hipGetLastError());
+        ph_end(h, PH_COST);
         if (h->nranks > 1 && h->xfn && h->xdev) {
             if (h->xfn(h->xctx, h->d_E2, 4, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
         }
         CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        CVX_HIP(hipStreamSynchronize(h->stream));
+        CVX_HIP(hipEventRecord(h->ev_step, h->stream));
+        // the candidate's rotation tables (needed only if the step is accepted) are made while the host decides
+        h->rt_valid[nxt] = false;
+        st = launch_pose_prepare(h, nxt);
+        if (st) return st;
+        CVX_HIP(hipEventSynchronize(h->ev_step));
         ph_collect(h);
         if (h->nranks > 1 && h->xfn && !h->xdev) {
             if (h->xfn(h->xctx, h->h_E2, 4, 0, nullptr)) return CVX_ERR_EXCHANGE;
@@ -587,6 +590,8 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(dev_alloc(&h->d_out_view, 3 * (size_t)V));
     h->n_cost_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (h->N + 255) / 256));
     CVX_TRY(dev_alloc(&h->d_cost_partial, (size_t)h->n_cost_blocks));
+    CVX_TRY(dev_alloc(&h->d_cost_view, (size_t)std::max(h->V, 1)));
+    CVX_HIP(hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
     CVX_TRY(dev_alloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
     CVX_HIP(hipHostMalloc((void **)&h->h_E2, 16 * sizeof(double), hipHostMallocDefault));
