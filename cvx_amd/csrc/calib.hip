@@ -2,6 +2,8 @@
 // Replaces the body of CameraCalibration::refine between "parameters packed" and
 // "parameters unpacked" (/root/reference/modules/calib/src/calibration.cpp:359-442).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -73,6 +75,8 @@ struct cvx_calib {
     double *d_ds_emb = nullptr, *h_ds_emb = nullptr, *d_dposes = nullptr, *d_out_view = nullptr;
     double *d_cost_partial = nullptr, *d_cost_view = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
     hipEvent_t ev_step = nullptr;
+    double *d_E2_map = nullptr;      // device view of h_E2 (host-mapped, fine-grained)
+    long long step_seq = 0;
     double *d_eval = nullptr;
     // device: damped reduced solve (solve_kernels.h)
     int npad = 32, nT = 1;
@@ -381,21 +385,40 @@ private:
             CVX_HIP(hipGetLastError());
         }
         ph_end(h, PH_BACKSUBST);
+        // one rank, no phase timing: the result lands in host-mapped memory and the host polls its sequence number
+        const bool polled = h->nranks == 1 && !h->timing && h->d_E2_map;
+        const double seq = (double)(++h->step_seq);
         ph_begin(h, PH_COST);
         hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V,
-                           h->d_out_view, h->V, h->d_E2);
+                           h->d_out_view, h->V, h->d_E2, polled ? h->d_E2_map : (double *)nullptr, seq);
         CVX_HIP(hipGetLastError());
         ph_end(h, PH_COST);
         if (h->nranks > 1 && h->xfn && h->xdev) {
             if (h->xfn(h->xctx, h->d_E2, 4, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
         }
-        CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        CVX_HIP(hipEventRecord(h->ev_step, h->stream));
+        if (!polled) {
+            CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            CVX_HIP(hipEventRecord(h->ev_step, h->stream));
+        }
         // the candidate's rotation tables (needed only if the step is accepted) are made while the host decides
         h->rt_valid[nxt] = false;
         st = launch_pose_prepare(h, nxt);
         if (st) return st;
-        CVX_HIP(hipEventSynchronize(h->ev_step));
+        if (polled) {
+            volatile const double *flag = h->h_E2 + 16;
+            const auto t0 = std::chrono::steady_clock::now();
+            long long spins = 0;
+            while (*flag != seq) {
+                if ((++spins & 0xffff) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+                    CVX_HIP(hipStreamSynchronize(h->stream));       // surfaces a kernel fault as a HIP error
+                    if (*flag != seq) { cvx::set_last_error("step result never arrived in host memory"); return CVX_ERR_HIP; }
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
+            CVX_HIP(hipEventSynchronize(h->ev_step));
+        }
         ph_collect(h);
         if (h->nranks > 1 && h->xfn && !h->xdev) {
             if (h->xfn(h->xctx, h->h_E2, 4, 0, nullptr)) return CVX_ERR_EXCHANGE;
@@ -594,7 +617,9 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_HIP(hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
     CVX_TRY(dev_alloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
-    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 16 * sizeof(double), hipHostMallocDefault));
+    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 32 * sizeof(double), hipHostMallocMapped));
+    std::memset(h->h_E2, 0, 32 * sizeof(double));
+    if (hipHostGetDevicePointer((void **)&h->d_E2_map, h->h_E2, 0) != hipSuccess) h->d_E2_map = nullptr;
     // damped reduced solve: (ns + 1) rows (the right-hand side rides as row ns), padded to 32-tiles
     h->nT = (h->ns + 1 + cvxs::TB - 1) / cvxs::TB;
     h->npad = h->nT * cvxs::TB;
@@ -659,7 +684,7 @@ extern "C" int cvx_calib_cost(cvx_calib *h, double *cost) {
                        (long long)h->N, h->d_cost_partial);
     CVX_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
-                       h->d_out_view, 0, h->d_E2);
+                       h->d_out_view, 0, h->d_E2, (double *)nullptr, 0.0);
     CVX_HIP(hipGetLastError());
     CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));

@@ -968,7 +968,8 @@ __device__ __forceinline__ double strided_sum_1024(const double *__restrict__ p,
 
 __global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict__ cost_partial, int n_partial,
                                                         const double *__restrict__ out_view, int V,
-                                                        double *__restrict__ E2) {
+                                                        double *__restrict__ E2, double *__restrict__ host_copy,
+                                                        double seq) {
     __shared__ double sh[4][16];
     double s[4];
     s[0] = strided_sum_1024(cost_partial, n_partial);
@@ -982,10 +983,27 @@ __global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict
         if (lane == 0) sh[k][wave] = s[k];
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const double *q = sh[threadIdx.x];
-        E2[threadIdx.x] = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
-                          (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+    if (threadIdx.x < 16) {
+        double v;
+        if (threadIdx.x < 4) {
+            const double *q = sh[threadIdx.x];
+            v = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+                (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+            E2[threadIdx.x] = v;
+        } else {
+            v = E2[threadIdx.x];              // the step's scalars, left there by k_solve_finish
+        }
+        // single-rank runs: the 16 doubles go straight into host-mapped memory, then a sequence number the host
+        // polls for (no copy kernel, no interrupt); the first wave holds all 16 writers, so no block barrier
+        if (host_copy) {
+            if (threadIdx.x < 15) host_copy[threadIdx.x] = v;
+            __threadfence_system();
+            __builtin_amdgcn_wave_barrier();
+            if (threadIdx.x == 0) {
+                host_copy[16] = seq;
+                __threadfence_system();
+            }
+        }
     }
 }
 
