@@ -374,6 +374,7 @@ def main():
                                    "CameraCalibration::refine LM iteration, k3 fixed, board points free",
                        "observations_per_gpu": N, "views_per_gpu": V, "shared_unknowns": ns,
                        "parallelism": "views sharded over %d GPU(s), one all-reduce of the reduced system per iteration" % world,
+                       "iterations_per_solve": ITERS_PER_SOLVE, "accepted_steps_in_last_solve": last.num_successful,
                        "final_cost_after_%d_iterations" % ITERS_PER_SOLVE: last.final_cost},
             "roofline": {"kernel": {"schur": "k_schur_syrk", "normal_eq": "k_normal_eq", "assemble": "k_group_sum+k_assemble",
                                     "backsubst": "k_backsubst", "cost": "k_cost",
