@@ -307,6 +307,26 @@ public:
 
     cvx::StepInfo try_step(const cvx_damping &d, double gtol, bool gradient_only) override {
         cvx::StepInfo out;
+        if (gradient_only) {
+            // cost and gradient only (the test Ceres makes after the last accepted step): the undamped
+            // linearisation without the Schur contraction, the reduced solve or a candidate
+            cvx_damping d0 = {0, 0, 0, 0};
+            out.status = linearize(h, d0, true, false);
+            if (out.status) return out;
+            const size_t nn = (size_t)h->ns * h->ns, tail = h->E_count - nn;
+            h->h_tail.resize(tail);
+            if (hipMemcpyAsync(h->h_tail.data(), h->d_E + nn, tail * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) { out.status = CVX_ERR_HIP; return out; }
+            ph_collect(h);
+            const double *gs = h->h_tail.data() + h->ns, *scal = h->h_tail.data() + 3 * (size_t)h->ns;
+            double gm = 0;
+            for (int q = 0; q < h->nranks; ++q) gm = std::max(gm, scal[2 + q]);
+            for (int i = 0; i < h->ns; ++i) gm = std::max(gm, std::fabs(gs[i]));
+            out.cost = 0.5 * scal[0];
+            out.grad_max = gm;
+            out.grad_converged = gm <= gtol;
+            return out;
+        }
         out.status = run_step(d);
         if (out.status) return out;
         const double *R = h->h_E2;
@@ -774,17 +794,19 @@ extern "C" int cvx_calib_time_schur(cvx_calib *h, int reps, double *ms_per_launc
     const cvx_damping d = {1e-4, 0.0, 1e-6, 1e32};
     int st = linearize(h, d, false, false);         // makes Z current
     if (st) return st;
-    hipEvent_t e0, e1;
-    CVX_HIP(hipEventCreate(&e0));
-    CVX_HIP(hipEventCreate(&e1));
+    struct Events {
+        hipEvent_t e[2] = {nullptr, nullptr};
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    CVX_HIP(hipEventCreate(&ev.e[0]));
+    CVX_HIP(hipEventCreate(&ev.e[1]));
     st = launch_schur(h);                            // one untimed launch
-    CVX_HIP(hipEventRecord(e0, h->stream));
+    CVX_HIP(hipEventRecord(ev.e[0], h->stream));
     for (int i = 0; i < reps && !st; ++i) st = launch_schur(h);
-    CVX_HIP(hipEventRecord(e1, h->stream));
+    CVX_HIP(hipEventRecord(ev.e[1], h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
     float ms = 0.f;
-    CVX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    CVX_HIP(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
     if (st) return st;
     *ms_per_launch = (double)ms / reps;
     return CVX_OK;
