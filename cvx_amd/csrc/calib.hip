@@ -226,12 +226,13 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         // fixed-order slab sums per camera and the scalars of this linearisation, one launch
         ReduceArgs ra;
         ra.njobs = 0; ra.C = h->C;
-        auto add = [&](const double *src, int n_out, const int *list, const int *off, double *dst) {
+        auto add = [&](const double *src, int n_out, const int *list, const int *off, double *dst, bool wide = false) {
             SumJob &j = ra.job[ra.njobs++];
-            j.src = src; j.stride = (size_t)n_out; j.n_out = n_out; j.blocks_x = (n_out + 63) / 64;
+            j.wide = wide ? 1 : 0;
+            j.src = src; j.stride = (size_t)n_out; j.n_out = n_out; j.blocks_x = wide ? (n_out + 255) / 256 : (n_out + 63) / 64;
             j.list = list; j.list_off = off; j.dst = dst;
         };
-        if (schur) add(h->d_slab_tile, h->nblk * 256, h->d_clist, h->d_clist_off, h->d_Tt);
+        if (schur) add(h->d_slab_tile, h->nblk * 256, h->d_clist, h->d_clist_off, h->d_Tt, true);
         if (h->pts_free) add(h->d_slab_pt, h->P * PT_ACC, h->d_glist, h->d_glist_off, h->d_Tpt);
         add(h->d_slab_cam, 256, h->d_glist, h->d_glist_off, h->d_Gcam);
         int blocks = 1;

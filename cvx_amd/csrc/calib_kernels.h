@@ -620,6 +620,7 @@ struct SumJob {
     const double *src;
     size_t stride;
     int n_out, blocks_x;
+    int wide;          // 1: a block is 256 consecutive outputs, each thread sums its whole (short) list
     const int *list, *list_off;
     double *dst;
 };
@@ -639,6 +640,25 @@ struct ReduceArgs {
 };
 
 __device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, double (*part)[64]) {
+    if (j.wide) {
+        // short lists (the Schur tiles: one entry per chunk of the camera): 2 KB coalesced rows, no LDS, sixteen
+        // independent loads in flight per thread
+        const int e = bx * 256 + threadIdx.x;
+        if (e >= j.n_out) return;
+        const int q0 = j.list_off[c], q1 = j.list_off[c + 1];
+        double s = 0.0;
+        int q = q0;
+        for (; q + 16 <= q1; q += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = j.src[(size_t)j.list[q + u] * j.stride + e];
+            s += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                 (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        }
+        for (; q < q1; ++q) s += j.src[(size_t)j.list[q] * j.stride + e];
+        j.dst[(size_t)c * j.n_out + e] = s;
+        return;
+    }
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = bx * 64 + lane;
     const int q0 = j.list_off[c], q1 = j.list_off[c + 1];
