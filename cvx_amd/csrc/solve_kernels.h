@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
         const int r = lane & 31;
         const bool panel = lane >= 32;
         double (*Dw)[TB + 1] = D[wave];
-        double row[TB];
+        double *mine = panel ? &P[wave][r][0] : &Dw[r][0];   // every lane publishes its row: no branch in the loop,
+        double row[TB];                                      // so the 32 columns are one block for the scheduler
         bool bad = false;
 #pragma unroll
         for (int c = 0; c < TB; ++c) row[c] = panel ? P[wave][r][c] : Dw[r][c];
@@ -160,11 +161,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
             const double val = t * ri;      // the diagonal lane has t == d: val = sqrt(d)
             row[j] = val;
             valprev = val;
-            if (!panel) Dw[r][j] = val;
-        }
-        if (panel) {
-#pragma unroll
-            for (int c = 0; c < TB; ++c) P[wave][r][c] = row[c];
+            mine[j] = val;
         }
         if (wave == 0 && __any(bad) && lane == 0) *fail = 1;
     }

@@ -695,10 +695,12 @@ int orc_calib_num_shared(const orc_calib_problem *pb) {
 }
 int orc_calib_num_free(const orc_calib_problem *pb) { return orc_calib_num_shared(pb) + 6 * pb->V; }
 
-double orc_calib_cost(const orc_calib_problem *pb, const double *intr, const double *poses,
-                      const double *points) {
+static int orc_threads;     /* defined with the linearisation below; 1 unless bench.py's baseline raises it */
+
+static double calib_cost_range(const orc_calib_problem *pb, const double *intr, const double *poses,
+                               const double *points, int v0, int v1) {
     double s = 0;
-    for (int v = 0; v < pb->V; ++v) {
+    for (int v = v0; v < v1; ++v) {
         const double *in = intr + 9 * pb->cam_of_view[v];
         for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
             double r[2];
@@ -706,6 +708,19 @@ double orc_calib_cost(const orc_calib_problem *pb, const double *intr, const dou
             s += r[0] * r[0] + r[1] * r[1];
         }
     }
+    return s;
+}
+
+double orc_calib_cost(const orc_calib_problem *pb, const double *intr, const double *poses,
+                      const double *points) {
+    const int T = orc_threads;
+    if (T <= 1) return 0.5 * calib_cost_range(pb, intr, poses, points, 0, pb->V);
+    double part[256], s = 0;
+    const int Tn = T > 256 ? 256 : T;
+#pragma omp parallel for num_threads(Tn) schedule(static, 1)
+    for (int t = 0; t < Tn; ++t)
+        part[t] = calib_cost_range(pb, intr, poses, points, (int)((long long)pb->V * t / Tn), (int)((long long)pb->V * (t + 1) / Tn));
+    for (int t = 0; t < Tn; ++t) s += part[t];
     return 0.5 * s;
 }
 
@@ -772,12 +787,21 @@ static void calib_lin_free(calib_lin *L) {
     free(L->S); free(L->rhs); free(L->T); free(L->Dcur);
 }
 
-static void calib_linearize_blocks(calib_lin *L, const double *intr, const double *poses, const double *points) {
+/* CPU baseline only (bench.py, SURVEY.md 8d "(ii) all cores"): with orc_threads > 1 the view loops below run on
+ * that many OpenMP threads over contiguous view ranges, each into private U / g / S accumulators that are added
+ * in thread order.  The sums are then associated differently from the one-thread path, so the CHECKER always
+ * runs with orc_threads == 1 (the default), which is also what the reference does (Ceres num_threads = 1,
+ * calibration.cpp:420-433 never sets it). */
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return orc_threads; }
+
+static double calib_linearize_range(calib_lin *L, const double *intr, const double *poses, const double *points,
+                                    int v0, int v1, double *U, double *gs) {
     const orc_calib_problem *pb = L->pb;
     const int nci = L->nci, ns = L->ns, fixp = pb->fix_points;
-    memset(L->U, 0, sizeof(double) * (size_t)ns * ns); memset(L->gs, 0, sizeof(double) * ns);
     double cost = 0;
-    for (int v = 0; v < pb->V; ++v) {
+    for (int v = v0; v < v1; ++v) {
         int c = pb->cam_of_view[v];
         double *Vv = L->Vv + 36 * v, *gv = L->gv + 6 * v, *Wc = L->Wc + (size_t)6 * nci * v;
         memset(Vv, 0, 36 * sizeof(double)); memset(gv, 0, 6 * sizeof(double));
@@ -800,22 +824,46 @@ static void calib_linearize_blocks(calib_lin *L, const double *intr, const doubl
                 }
                 for (int a = 0; a < nci; ++a) {
                     int ia = c * nci + a;
-                    for (int b = 0; b < nci; ++b) L->U[(size_t)ia * ns + c * nci + b] += jc[a] * jc[b];
-                    L->gs[ia] += jc[a] * r[k];
+                    for (int b = 0; b < nci; ++b) U[(size_t)ia * ns + c * nci + b] += jc[a] * jc[b];
+                    gs[ia] += jc[a] * r[k];
                     if (!fixp) for (int b = 0; b < 3; ++b) {
                         int ib = L->off_pt + 3 * pid + b;
-                        L->U[(size_t)ia * ns + ib] += jc[a] * jx[b];
-                        L->U[(size_t)ib * ns + ia] += jc[a] * jx[b];
+                        U[(size_t)ia * ns + ib] += jc[a] * jx[b];
+                        U[(size_t)ib * ns + ia] += jc[a] * jx[b];
                     }
                 }
                 if (!fixp) for (int a = 0; a < 3; ++a) {
                     int ia = L->off_pt + 3 * pid + a;
-                    for (int b = 0; b < 3; ++b) L->U[(size_t)ia * ns + L->off_pt + 3 * pid + b] += jx[a] * jx[b];
-                    L->gs[ia] += jx[a] * r[k];
+                    for (int b = 0; b < 3; ++b) U[(size_t)ia * ns + L->off_pt + 3 * pid + b] += jx[a] * jx[b];
+                    gs[ia] += jx[a] * r[k];
                 }
             }
         }
     }
+    return cost;
+}
+
+static void calib_linearize_blocks(calib_lin *L, const double *intr, const double *poses, const double *points) {
+    const orc_calib_problem *pb = L->pb;
+    const int ns = L->ns, T = orc_threads;
+    memset(L->U, 0, sizeof(double) * (size_t)ns * ns); memset(L->gs, 0, sizeof(double) * ns);
+    if (T <= 1) { L->cost = 0.5 * calib_linearize_range(L, intr, poses, points, 0, pb->V, L->U, L->gs); return; }
+    const size_t per = (size_t)ns * ns + ns + 1;
+    double *acc = calloc(per * T, sizeof(double));
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; ++t) {
+        double *a = acc + per * t;
+        a[per - 1] = calib_linearize_range(L, intr, poses, points, (int)((long long)pb->V * t / T),
+                                           (int)((long long)pb->V * (t + 1) / T), a, a + (size_t)ns * ns);
+    }
+    double cost = 0;
+    for (int t = 0; t < T; ++t) {
+        const double *a = acc + per * t;
+        for (size_t i = 0; i < (size_t)ns * ns; ++i) L->U[i] += a[i];
+        for (int i = 0; i < ns; ++i) L->gs[i] += a[(size_t)ns * ns + i];
+        cost += a[per - 1];
+    }
+    free(acc);
     L->cost = 0.5 * cost;
 }
 
@@ -849,16 +897,14 @@ static void chol6_solve(const double L[36], double *b, int stride) {
 
 /* Builds S and rhs for damping D = [Ds (ns) | Dp (6V)] ordering of the FREE vector
  * [shared | poses] used internally; returns 0 if some pose block is not PD. */
-static int calib_build_reduced(calib_lin *L, const double *Ds, const double *Dp, double *S, double *gred) {
+static int calib_reduce_range(calib_lin *L, const double *Dp, double *S, double *gred, int v0, int v1) {
     const orc_calib_problem *pb = L->pb;
     const int nci = L->nci, ns = L->ns;
-    memcpy(S, L->U, sizeof(double) * (size_t)ns * ns);
-    for (int i = 0; i < ns; ++i) { S[(size_t)i * ns + i] += Ds[i]; gred[i] = L->gs[i]; }
     int *cols = malloc(sizeof(int) * (nci + 3 * (size_t)pb->P + 3));
     double *Wrow = malloc(sizeof(double) * 6 * (nci + 3 * (size_t)pb->P + 3));
     double *Trow = malloc(sizeof(double) * 6 * (nci + 3 * (size_t)pb->P + 3));
     int ok = 1;
-    for (int v = 0; v < pb->V && ok; ++v) {
+    for (int v = v0; v < v1 && ok; ++v) {
         int c = pb->cam_of_view[v];
         int nobs = pb->view_off[v + 1] - pb->view_off[v];
         int k = nci + (pb->fix_points ? 0 : 3 * nobs);
@@ -892,6 +938,30 @@ static int calib_build_reduced(calib_lin *L, const double *Ds, const double *Dp,
         }
     }
     free(cols); free(Wrow); free(Trow);
+    return ok;
+}
+
+static int calib_build_reduced(calib_lin *L, const double *Ds, const double *Dp, double *S, double *gred) {
+    const orc_calib_problem *pb = L->pb;
+    const int ns = L->ns, T = orc_threads;
+    memcpy(S, L->U, sizeof(double) * (size_t)ns * ns);
+    for (int i = 0; i < ns; ++i) { S[(size_t)i * ns + i] += Ds[i]; gred[i] = L->gs[i]; }
+    if (T <= 1) return calib_reduce_range(L, Dp, S, gred, 0, pb->V);
+    const size_t per = (size_t)ns * ns + ns;
+    double *acc = calloc(per * T, sizeof(double));
+    int *okt = calloc(T, sizeof(int));
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; ++t)
+        okt[t] = calib_reduce_range(L, Dp, acc + per * t, acc + per * t + (size_t)ns * ns,
+                                    (int)((long long)pb->V * t / T), (int)((long long)pb->V * (t + 1) / T));
+    int ok = 1;
+    for (int t = 0; t < T; ++t) {
+        const double *a = acc + per * t;
+        ok = ok && okt[t];
+        for (size_t i = 0; i < (size_t)ns * ns; ++i) S[i] += a[i];
+        for (int i = 0; i < ns; ++i) gred[i] += a[(size_t)ns * ns + i];
+    }
+    free(acc); free(okt);
     return ok;
 }
 

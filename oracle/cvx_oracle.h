@@ -206,6 +206,11 @@ int orc_lu_solve(int n, const double *A, const double *b, double *x);
 /* dense SPD solve used by the drivers (Cholesky); returns 0 on failure */
 int orc_cholesky_solve(int n, double *A /* destroyed */, double *b /* in: rhs, out: x */);
 
+/* CPU-baseline knob (bench.py only): OpenMP threads for the per-view loops of the calibration model; 1 (the
+ * default, and what every test uses) keeps the single-thread summation order. */
+void orc_set_threads(int n);
+int orc_get_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,12 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
 
 
+def set_threads(n):
+    """OpenMP threads of the calibration model's per-view loops (bench.py's all-cores baseline only; 1 = the
+    checker's single-thread summation order, the default)."""
+    lib().orc_set_threads(int(n))
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -107,6 +113,8 @@ def lib():
         L.orc_lm_nielsen_der.argtypes = [LM_FUNC, LM_FUNC, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_void_p]
         L.orc_lm_nielsen_der.restype = C.c_int
         L.orc_cholesky_solve.argtypes = [C.c_int, dp, dp]; L.orc_cholesky_solve.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]; L.orc_set_threads.restype = None
+        L.orc_get_threads.argtypes = []; L.orc_get_threads.restype = C.c_int
         tp = C.POINTER(ToolBAProblem)
         L.orc_toolba_analytic.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]
         L.orc_toolba_autodiff.argtypes = L.orc_toolba_analytic.argtypes

@@ -193,6 +193,27 @@ def test_reduced_system_equals_dense_schur_complement(orc):
     assert abs(cost - 0.5 * r @ r) <= 1e-13 * cost
 
 
+def test_threaded_baseline_path_agrees_with_single_thread(orc):
+    """bench.py's all-cores CPU baseline (orc_set_threads > 1) sums per-thread partial systems: same numbers up to
+    the re-association, and the single-thread order is restored afterwards."""
+    import cvx_amd
+    d = cvx_amd.synth_calib(2, 7, 6, 5, 123, ragged=2)
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    ns = 8 * d["C"] + 3 * d["P"]
+    Ds, Dp = np.full(ns, 0.3), np.full(6 * d["V"], 0.2)
+    S1, g1, c1 = o.reduced_system(d["intr_init"], d["poses_init"], d["points_init"], Dp, Ds)
+    orc.set_threads(3)
+    try:
+        S3, g3, c3 = o.reduced_system(d["intr_init"], d["poses_init"], d["points_init"], Dp, Ds)
+        k3 = o.cost(d["intr_init"], d["poses_init"], d["points_init"])
+    finally:
+        orc.set_threads(1)
+    assert rel_err(S3, S1) < 1e-13 and rel_err(g3, g1) < 1e-12
+    assert abs(c3 - c1) <= 1e-14 * c1 and abs(k3 - c1) <= 1e-14 * c1
+    S1b, g1b, _ = o.reduced_system(d["intr_init"], d["poses_init"], d["points_init"], Dp, Ds)
+    assert np.array_equal(S1b, S1) and np.array_equal(g1b, g1)
+
+
 def test_dense_levmar_restatement_on_calibration_functor(orc):
     """Reference levmar vs its restatement, both driven by the oracle's reprojection callbacks on BASELINE
     config 1 (2160 residuals x 291 parameters, the blocked J^T J path): bit-identical."""
