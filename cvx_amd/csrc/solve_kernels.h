@@ -69,6 +69,70 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
+// Sixteen columns [J0, J0 + 16) of the left-looking factor loop over the 64 rows a wave holds, software-pipelined:
+// while column j is being finished (its diagonal -> rsqrt -> scale chain), the dot product of column j + 1 over
+// every term of this half but the newest is already accumulated from LDS broadcasts of pivot row j + 1 (all
+// published at least one column earlier); the newest term, L[j+1][j], travels by readlane.  The LDS round trip is
+// off the serial chain.  Terms of earlier halves must already be folded into row[].
+template <int J0>
+__device__ __forceinline__ void chol_columns(double (&row)[TB], const double (*Dw)[TB + 1], double *mine, int lane, bool &bad) {
+    (void)lane;
+    double tpart = row[J0];     // row[j] - sum_{J0 <= m <= j-2} L[r][m] L[j][m]
+    double valprev = 0.0;
+    // The column's serial chain is eight dependent fp64 operations; a wave issues in order, so the independent
+    // dot-product fmas are placed by hand into the chain's stalls, one group after each link (the compiler's
+    // scheduler puts them all behind the chain).  CHOL_FENCE keeps that order.
+#define CHOL_FENCE() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int j = J0; j < J0 + 16; ++j) {
+        const int nd = (j + 1 < J0 + 16) ? j - J0 : 0;     // terms of column j + 1's dot product available now
+        double pl[16];          // pivot row j + 1, every read issued before the first use
+#pragma unroll
+        for (int i = 0; i < nd; ++i) pl[i] = Dw[j + 1][J0 + i];
+        double acc[4] = {(j + 1 < J0 + 16) ? row[j + 1] : 0.0, 0.0, 0.0, 0.0};
+        auto dots = [&](int g) {    // group g of five
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < nd && i >= g * nd / 5 && i < (g + 1) * nd / 5)
+                    acc[i & 3] = fma((i & 3) ? row[J0 + i] : -row[J0 + i], pl[i], acc[i & 3]);
+        };
+        CHOL_FENCE();
+        double t = tpart;
+        if (j > J0) t = fma(-valprev, readlane_f64(valprev, j), t);
+        const double d = readlane_f64(t, j);
+        // 1 / sqrt(d): hardware estimate + one Newton-Raphson step of third order (no special-case
+        // handling: d <= 0 or non-finite gives NaN, which the flag reports)
+        const double y0 = __builtin_amdgcn_rsq(d);
+        CHOL_FENCE();
+        dots(0);
+        CHOL_FENCE();
+        const double dy = -d * y0;
+        CHOL_FENCE();
+        dots(1);
+        CHOL_FENCE();
+        const double e = fma(dy, y0, 1.0);
+        CHOL_FENCE();
+        dots(2);
+        CHOL_FENCE();
+        const double ye = y0 * e, h = fma(e, 0.375, 0.5);
+        CHOL_FENCE();
+        dots(3);
+        CHOL_FENCE();
+        const double ri = fma(ye, h, y0);
+        CHOL_FENCE();
+        dots(4);
+        CHOL_FENCE();
+        const double val = t * ri;      // the diagonal lane has t == d: val = sqrt(d)
+        bad = bad || !(d > 0.0 && d < 1.7e308);
+        row[j] = val;
+        valprev = val;
+        mine[j] = val;
+        tpart = (acc[0] - acc[1]) - (acc[2] + acc[3]);
+        CHOL_FENCE();
+    }
+#undef CHOL_FENCE
+}
+
 // -----------------------------------------------------------------------------------------
 // One tile column k of the factorisation.  Block b owns trailing tile (ti, tj), k < tj <= ti.
 // Waves 0 and 1 each run the left-looking column loop over 64 rows: lanes 0..31 hold the rows of
@@ -84,6 +148,7 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld, int n, int k, int nT, int *fail) {
     __shared__ double D[2][TB][TB + 1];
     __shared__ double P[2][TB][TB + 1];
+    __shared__ double X[2][64][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     CSTAMP(0);
     const int ntr = nT - 1 - k;
@@ -119,50 +184,48 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
     __syncthreads();
     CSTAMP(1);
     if (wave < 2) {
-        // left-looking column loop, software-pipelined: while column j is being finished (its diagonal ->
-        // rsqrt -> scale chain), the dot product of column j + 1 over every term but the newest is already
-        // accumulated from LDS broadcasts of pivot row j + 1 (all published at least one column earlier);
-        // the newest term, L[j+1][j], travels by readlane.  The LDS round trip is off the serial chain.
+        // 64 rows per wave (lanes 0..31 the diagonal tile, 32..63 this wave's panel tile), one lane per row, the
+        // row in registers.  Two half-tiles of 16 columns (chol_columns), and between them the rank-16 update of
+        // columns 16..31 by the finished columns 0..15 on MFMA -- done lane by lane it would be 256 of the 496
+        // fma + LDS-broadcast pairs of the whole tile, which a single wave issues at ~12 cycles each.
         const int r = lane & 31;
         const bool panel = lane >= 32;
         double (*Dw)[TB + 1] = D[wave];
-        double *mine = panel ? &P[wave][r][0] : &Dw[r][0];   // every lane publishes its row: no branch in the loop,
-        double row[TB];                                      // so the 32 columns are one block for the scheduler
+        double (*Pw)[TB + 1] = P[wave];
+        double *mine = panel ? &Pw[r][0] : &Dw[r][0];   // every lane publishes its row: no branch in the loops
+        double row[TB];
         bool bad = false;
 #pragma unroll
-        for (int c = 0; c < TB; ++c) row[c] = panel ? P[wave][r][c] : Dw[r][c];
-        double tpart = row[0];      // row[j] - sum_{m <= j-2} L[r][m] L[j][m]
-        double valprev = 0.0;
+        for (int c = 0; c < TB; ++c) row[c] = mine[c];
+        chol_columns<0>(row, Dw, mine, lane, bad);
+        {
+            // C[R][16 + c] = sum_{m < 16} L[R][m] L[16 + c][m] for the rows R >= 16 of the wave's 64 (row block 0 is
+            // the upper triangle of the diagonal tile: not needed).  The wave's own LDS writes above are ordered
+            // before these reads by the LDS queue; the asm only stops the compiler from moving them.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f64x4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1, acc3 = acc1;
 #pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            double t = tpart;
-            if (j > 0) t = fma(-valprev, readlane_f64(valprev, j), t);
-            const double d = readlane_f64(t, j);
-            if (j + 1 < TB) {       // independent of this column's result
-                double pl[TB];      // pivot row j + 1, every read issued before the first use
-#pragma unroll
-                for (int m = 0; m < j; ++m) pl[m] = Dw[j + 1][m];
-                double t0 = row[j + 1], t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-                for (int m = 0; m < j; ++m) {
-                    if ((m & 3) == 0) t0 = fma(-row[m], pl[m], t0);
-                    else if ((m & 3) == 1) t1 = fma(row[m], pl[m], t1);
-                    else if ((m & 3) == 2) t2 = fma(row[m], pl[m], t2);
-                    else t3 = fma(row[m], pl[m], t3);
-                }
-                tpart = (t0 - t1) - (t2 + t3);
+            for (int ks = 0; ks < 4; ++ks) {
+                const double b = Dw[16 + cq][4 * ks + kq];
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pw[cq][4 * ks + kq], b, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pw[16 + cq][4 * ks + kq], b, acc3, 0, 0, 0);
             }
-            // 1 / sqrt(d): hardware estimate + one Newton-Raphson step of third order (no special-case
-            // handling: d <= 0 or non-finite gives NaN, which the flag below reports)
-            bad = bad || !(d > 0.0 && d < 1.7e308);
-            const double y0 = __builtin_amdgcn_rsq(d);
-            const double e = fma(-d * y0, y0, 1.0);
-            const double ri = fma(y0 * e, fma(e, 0.375, 0.5), y0);
-            const double val = t * ri;      // the diagonal lane has t == d: val = sqrt(d)
-            row[j] = val;
-            valprev = val;
-            mine[j] = val;
+            // accumulator layout (lane = cq + 16 kq holds rows kq + 4 q of column cq) -> one row per lane, through LDS
+            double (*Xw)[17] = X[wave];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Xw[16 + kq + 4 * q][cq] = acc1[q];
+                Xw[32 + kq + 4 * q][cq] = acc2[q];
+                Xw[48 + kq + 4 * q][cq] = acc3[q];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane >= 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) row[16 + c] -= Xw[lane][c];
+            }
         }
+        chol_columns<16>(row, Dw, mine, lane, bad);
         if (wave == 0 && __any(bad) && lane == 0) *fail = 1;
     }
     __syncthreads();
