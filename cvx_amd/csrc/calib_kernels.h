@@ -155,23 +155,29 @@ __device__ __forceinline__ void reproj_jacobian(const Intr &in, const double *__
 // -----------------------------------------------------------------------------------------
 // Two consecutive observations per lane, so that every plane is written with 16-byte stores
 // (1 KiB per wave instruction); the odd tail observation, if any, goes through the same code with
-// the second slot masked.
-__global__ void __launch_bounds__(64) k_eval(const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
-                                              const int *__restrict__ point_id, const double *__restrict__ obs_x,
-                                              const double *__restrict__ obs_y, const double *__restrict__ intr,
-                                              const double *__restrict__ points, const double *__restrict__ rt,
-                                              long long N, double *__restrict__ out) {
-    const long long o = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
-    if (o >= N) return;
-    const bool two = o + 1 < N;
+// the second slot masked.  A workgroup's 512 observations belong to a handful of consecutive views
+// (5 at 108 per view): their rotation tables and intrinsics are staged in LDS once (49 doubles per
+// view), so a lane issues ~50 broadcast ds_read_b128 instead of 96 global loads and the memory pipe
+// is left to the stores.  Workgroups that span more than EVAL_VIEWS views (many near-empty views)
+// read the tables from global memory as before.
+constexpr int EVAL_THREADS = 256;
+constexpr int EVAL_VIEWS = 24;
+constexpr int EVAL_PITCH = 50;      // 40 table + 9 intrinsics + 1 pad: rows stay 16-byte aligned
+
+template <typename TABLE>
+__device__ __forceinline__ void eval_pair(long long o, bool two, long long N, const int *__restrict__ view_id,
+                                          const int *__restrict__ point_id, const double *__restrict__ obs_x,
+                                          const double *__restrict__ obs_y, const double *__restrict__ points,
+                                          double *__restrict__ out, TABLE table) {
     double r[2][2], Jp[2][12], Jc[2][18], Jx[2][6];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const long long ou = (u == 0 || two) ? o + u : o;
         const int v = view_id[ou], pid = point_id[ou];
-        const Intr in = load_intr(intr + 9 * cam_of_view[v]);
+        const double *t = table(v);
+        const Intr in = load_intr(t + RT_STRIDE);
         const double *X = points + 3 * pid;
-        reproj_jacobian(in, rt + (size_t)v * RT_STRIDE, X[0], X[1], X[2], obs_x[ou], obs_y[ou], r[u][0], r[u][1], Jp[u], Jc[u], Jx[u]);
+        reproj_jacobian(in, t, X[0], X[1], X[2], obs_x[ou], obs_y[ou], r[u][0], r[u][1], Jp[u], Jc[u], Jx[u]);
     }
     // planes start at multiples of N doubles: 16-byte aligned pairs need N even
     if (two && !(N & 1)) {
@@ -203,6 +209,45 @@ __global__ void __launch_bounds__(64) k_eval(const int *__restrict__ view_id, co
 #pragma unroll
             for (int i = 0; i < 6; ++i) p[(long long)i * N] = Jx[u][i];
         }
+    }
+}
+
+__global__ void __launch_bounds__(EVAL_THREADS) k_eval(const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
+                                                        const int *__restrict__ point_id, const double *__restrict__ obs_x,
+                                                        const double *__restrict__ obs_y, const double *__restrict__ intr,
+                                                        const double *__restrict__ points, const double *__restrict__ rt,
+                                                        long long N, double *__restrict__ out) {
+    __shared__ __align__(16) double tab[EVAL_VIEWS * EVAL_PITCH];
+    const long long o0 = 2LL * blockIdx.x * EVAL_THREADS;      // < N by the grid size
+    const long long o1 = (o0 + 2 * EVAL_THREADS < N ? o0 + 2 * EVAL_THREADS : N) - 1;
+    const int v0 = view_id[o0], nv = view_id[o1] - v0 + 1;     // view ids ascend with the observation index
+    const bool staged = nv <= EVAL_VIEWS;
+    if (staged) {
+        for (int e = threadIdx.x; e < nv * EVAL_PITCH; e += EVAL_THREADS) {
+            const int vv = e / EVAL_PITCH, k = e - vv * EVAL_PITCH;
+            double x = 0.0;
+            if (k < RT_STRIDE) x = rt[(size_t)(v0 + vv) * RT_STRIDE + k];
+            else if (k < RT_STRIDE + 9) x = intr[9 * cam_of_view[v0 + vv] + (k - RT_STRIDE)];
+            tab[e] = x;
+        }
+    }
+    __syncthreads();
+    const long long o = o0 + 2 * threadIdx.x;
+    if (o >= N) return;
+    const bool two = o + 1 < N;
+    if (staged) {
+        eval_pair(o, two, N, view_id, point_id, obs_x, obs_y, points, out,
+                  [&](int v) -> const double * { return tab + (v - v0) * EVAL_PITCH; });
+    } else {
+        // per-lane copy of the view's 49 doubles in registers (the slow path: correctness only)
+        double loc[RT_STRIDE + 9];
+        eval_pair(o, two, N, view_id, point_id, obs_x, obs_y, points, out, [&](int v) -> const double * {
+#pragma unroll
+            for (int k = 0; k < RT_STRIDE; ++k) loc[k] = rt[(size_t)v * RT_STRIDE + k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) loc[RT_STRIDE + k] = intr[9 * cam_of_view[v] + k];
+            return loc;
+        });
     }
 }
 
