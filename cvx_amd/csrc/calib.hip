@@ -723,7 +723,7 @@ extern "C" int cvx_calib_evaluate_device(cvx_calib *h, void **device_buffer) {
     int st = launch_pose_prepare(h, h->cur);
     if (st) return st;
     if (h->N > 0) {
-        hipLaunchKernelGGL(k_eval, dim3((unsigned)((h->N + 2 * EVAL_THREADS - 1) / (2 * EVAL_THREADS))), dim3(EVAL_THREADS), 0, h->stream, h->d_view_id,
+        hipLaunchKernelGGL(k_eval, dim3((unsigned)((h->N + EVAL_THREADS - 1) / EVAL_THREADS)), dim3(EVAL_THREADS), 0, h->stream, h->d_view_id,
                            h->d_cam_of_view, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur],
                            h->d_points[h->cur], h->d_rt[h->cur], (long long)h->N, h->d_eval);
         CVX_HIP(hipGetLastError());

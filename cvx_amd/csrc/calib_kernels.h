@@ -153,62 +153,56 @@ __device__ __forceinline__ void reproj_jacobian(const Intr &in, const double *__
 // K1: evaluation mode -- residuals and Jacobian blocks materialised as component planes
 // out layout (doubles): r[2][N] | Jc[18][N] | Jp[12][N] | Jx[6][N]
 // -----------------------------------------------------------------------------------------
-// Two consecutive observations per lane, so that every plane is written with 16-byte stores
-// (1 KiB per wave instruction); the odd tail observation, if any, goes through the same code with
-// the second slot masked.  A workgroup's 512 observations belong to a handful of consecutive views
-// (5 at 108 per view): their rotation tables and intrinsics are staged in LDS once (49 doubles per
-// view), so a lane issues ~50 broadcast ds_read_b128 instead of 96 global loads and the memory pipe
-// is left to the stores.  Workgroups that span more than EVAL_VIEWS views (many near-empty views)
-// read the tables from global memory as before.
+// One observation per lane (38 outputs = 76 VGPRs: twice the occupancy two observations per lane allow), and
+// still nothing but 16-byte stores: lanes 2i and 2i+1 trade halves with a DPP swap -- the even lane writes the
+// pair's planes 0..18, the odd lane planes 19..37 (two 512-byte runs per wave instruction).  That needs N even,
+// so that every plane starts 16-byte aligned and every observation has its partner; an odd N takes 8-byte stores.
+// A workgroup's 256 observations belong to a handful of consecutive views (3 at 108 per view): their rotation
+// tables and intrinsics are staged in LDS once (49 doubles per view), so a lane issues ~25 broadcast
+// ds_read_b128 instead of 48 global loads and the memory pipe is left to the stores.  Workgroups that span more
+// than EVAL_VIEWS views (many near-empty views) read the tables from global memory.
 constexpr int EVAL_THREADS = 256;
 constexpr int EVAL_VIEWS = 24;
 constexpr int EVAL_PITCH = 50;      // 40 table + 9 intrinsics + 1 pad: rows stay 16-byte aligned
 
-template <typename TABLE>
-__device__ __forceinline__ void eval_pair(long long o, bool two, long long N, const int *__restrict__ view_id,
-                                          const int *__restrict__ point_id, const double *__restrict__ obs_x,
-                                          const double *__restrict__ obs_y, const double *__restrict__ points,
-                                          double *__restrict__ out, TABLE table) {
-    double r[2][2], Jp[2][12], Jc[2][18], Jx[2][6];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const long long ou = (u == 0 || two) ? o + u : o;
-        const int v = view_id[ou], pid = point_id[ou];
-        const double *t = table(v);
-        const Intr in = load_intr(t + RT_STRIDE);
+__device__ __forceinline__ double dpp_swap_neighbour(double x) {     // lane i <-> lane i ^ 1 (quad_perm [1,0,3,2])
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void eval_one(long long o, long long N, int pid, double ox, double oy,
+                                         const double *__restrict__ points, double *__restrict__ out,
+                                         const double *t, const double *ip) {
+    double val[38];     // plane order: r[2] | Jc[18] | Jp[12] | Jx[6]
+    {
+        double Jp[12], Jc[18], Jx[6];
+        const Intr in = load_intr(ip);
         const double *X = points + 3 * pid;
-        reproj_jacobian(in, t, X[0], X[1], X[2], obs_x[ou], obs_y[ou], r[u][0], r[u][1], Jp[u], Jc[u], Jx[u]);
+        reproj_jacobian(in, t, X[0], X[1], X[2], ox, oy, val[0], val[1], Jp, Jc, Jx);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) val[2 + i] = Jc[i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) val[20 + i] = Jp[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) val[32 + i] = Jx[i];
     }
-    // planes start at multiples of N doubles: 16-byte aligned pairs need N even
-    if (two && !(N & 1)) {
-        double2 *p = (double2 *)(out + o);
+    if (!(N & 1)) {
+        const bool odd = o & 1;
+        double2 *p = (double2 *)(out + (o & ~1LL) + (odd ? 19 * N : 0));
         const long long h = N >> 1;
-        p[0] = double2{r[0][0], r[1][0]}; p[h] = double2{r[0][1], r[1][1]};
-        p += 2 * h;
 #pragma unroll
-        for (int i = 0; i < 18; ++i) p[(long long)i * h] = double2{Jc[0][i], Jc[1][i]};
-        p += 18 * h;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) p[(long long)i * h] = double2{Jp[0][i], Jp[1][i]};
-        p += 12 * h;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) p[(long long)i * h] = double2{Jx[0][i], Jx[1][i]};
-    } else {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !two) break;
-            double *p = out + o + u;
-            p[0] = r[u][0]; p[N] = r[u][1];
-            p += 2 * N;
-#pragma unroll
-            for (int i = 0; i < 18; ++i) p[(long long)i * N] = Jc[u][i];
-            p += 18 * N;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) p[(long long)i * N] = Jp[u][i];
-            p += 12 * N;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) p[(long long)i * N] = Jx[u][i];
+        for (int s = 0; s < 19; ++s) {
+            const double keep = odd ? val[19 + s] : val[s];
+            const double give = odd ? val[s] : val[19 + s];
+            const double got = dpp_swap_neighbour(give);
+            p[(long long)s * h] = odd ? double2{got, keep} : double2{keep, got};
         }
+    } else {
+        double *p = out + o;
+#pragma unroll
+        for (int i = 0; i < 38; ++i) p[(long long)i * N] = val[i];
     }
 }
 
@@ -218,9 +212,9 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval(const int *__restrict__ v
                                                         const double *__restrict__ points, const double *__restrict__ rt,
                                                         long long N, double *__restrict__ out) {
     __shared__ __align__(16) double tab[EVAL_VIEWS * EVAL_PITCH];
-    const long long o0 = 2LL * blockIdx.x * EVAL_THREADS;      // < N by the grid size
-    const long long o1 = (o0 + 2 * EVAL_THREADS < N ? o0 + 2 * EVAL_THREADS : N) - 1;
-    const int v0 = view_id[o0], nv = view_id[o1] - v0 + 1;     // view ids ascend with the observation index
+    const long long o0 = (long long)blockIdx.x * EVAL_THREADS;      // < N by the grid size
+    const long long o1 = (o0 + EVAL_THREADS < N ? o0 + EVAL_THREADS : N) - 1;
+    const int v0 = view_id[o0], nv = view_id[o1] - v0 + 1;         // view ids ascend with the observation index
     const bool staged = nv <= EVAL_VIEWS;
     if (staged) {
         for (int e = threadIdx.x; e < nv * EVAL_PITCH; e += EVAL_THREADS) {
@@ -232,22 +226,15 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval(const int *__restrict__ v
         }
     }
     __syncthreads();
-    const long long o = o0 + 2 * threadIdx.x;
-    if (o >= N) return;
-    const bool two = o + 1 < N;
+    const long long o = o0 + threadIdx.x;
+    if (o >= N) return;         // N even: a lane and its partner leave together
+    const int v = view_id[o], pid = point_id[o];
+    const double ox = obs_x[o], oy = obs_y[o];
     if (staged) {
-        eval_pair(o, two, N, view_id, point_id, obs_x, obs_y, points, out,
-                  [&](int v) -> const double * { return tab + (v - v0) * EVAL_PITCH; });
+        const double *t = tab + (v - v0) * EVAL_PITCH;
+        eval_one(o, N, pid, ox, oy, points, out, t, t + RT_STRIDE);
     } else {
-        // per-lane copy of the view's 49 doubles in registers (the slow path: correctness only)
-        double loc[RT_STRIDE + 9];
-        eval_pair(o, two, N, view_id, point_id, obs_x, obs_y, points, out, [&](int v) -> const double * {
-#pragma unroll
-            for (int k = 0; k < RT_STRIDE; ++k) loc[k] = rt[(size_t)v * RT_STRIDE + k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) loc[RT_STRIDE + k] = intr[9 * cam_of_view[v] + k];
-            return loc;
-        });
+        eval_one(o, N, pid, ox, oy, points, out, rt + (size_t)v * RT_STRIDE, intr + 9 * cam_of_view[v]);
     }
 }
 
