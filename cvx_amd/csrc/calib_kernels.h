@@ -197,7 +197,9 @@ __device__ __forceinline__ void eval_one(long long o, long long N, int pid, doub
             const double keep = odd ? val[19 + s] : val[s];
             const double give = odd ? val[s] : val[19 + s];
             const double got = dpp_swap_neighbour(give);
-            p[(long long)s * h] = odd ? double2{got, keep} : double2{keep, got};
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d pr = {odd ? got : keep, odd ? keep : got};
+            __builtin_nontemporal_store(pr, (v2d *)&p[(long long)s * h]);
         }
     } else {
         double *p = out + o;
