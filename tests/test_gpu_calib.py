@@ -47,6 +47,29 @@ def test_residuals_and_jacobians_match_oracle(orc, case):
     g.close()
 
 
+def test_evaluation_with_many_near_empty_views(orc):
+    """k_eval stages the tables of a workgroup's views in LDS when they are at most 24; 256 consecutive
+    observations of 3..9-marker views span more, which takes the unstaged path -- with an even and an odd N
+    (16-byte pair stores / 8-byte stores)."""
+    seen = set()
+    for seed in range(30, 40):
+        d = cvx_amd.synth_calib(2, 60, 3, 3, seed, ragged=6)
+        if d["N"] % 2 in seen:
+            continue
+        seen.add(d["N"] % 2)
+        assert d["V"] == 120 and d["N"] > 256 and d["N"] / d["V"] < 256 / 24
+        args = (d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 2, 9)
+        g, o = cvx_amd.Calib(*args), orc.Calib(*args)
+        g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+        _, r, Jc, Jp, Jx = g.evaluate()
+        ro, Jco, Jpo, Jxo = o.eval(d["intr_init"], d["poses_init"], d["points_init"])
+        assert rel_err(r, ro) < 1e-12
+        for a, b in ((Jc, Jco), (Jp, Jpo), (Jx, Jxo)):
+            assert rel_err(a, b) < 1e-12
+        g.close()
+    assert seen == {0, 1}
+
+
 def test_functor_against_50_digit_fixture():
     """r and the 2x(9|6|3) Jacobian blocks from the HIP evaluation kernel vs the mpmath values, including the
     theta -> 0 branch of AngleAxisRotatePoint (poses 0 and 1) and a camera with k3 != 0."""
