@@ -399,8 +399,8 @@ def main():
                        "parallelism": "views sharded over %d GPU(s), one all-reduce of the reduced system per iteration" % world,
                        "iterations_per_solve": ITERS_PER_SOLVE, "accepted_steps_in_last_solve": last.num_successful,
                        "final_cost_after_%d_iterations" % ITERS_PER_SOLVE: last.final_cost},
-            "roofline": {"kernel": {"schur": "k_schur_syrk", "normal_eq": "k_normal_eq", "assemble": "k_group_sum+k_assemble",
-                                    "backsubst": "k_backsubst", "cost": "k_cost",
+            "roofline": {"kernel": {"schur": "k_schur_syrk4", "normal_eq": "k_normal_eq", "assemble": "k_reduce_all+k_assemble",
+                                    "backsubst": "k_backsubst_cost", "cost": "k_final_scalars",
                                     "solve": "k_damp_prepare+k_chol_step+k_solve_finish"}[dom],
                          "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,

@@ -59,6 +59,7 @@ struct cvx_calib {
     std::vector<int> h_cam_of_view, h_view_off;
     // device: static
     int *d_view_off = nullptr, *d_cam_of_view = nullptr, *d_point_id = nullptr, *d_view_id = nullptr;
+    K4Task *d_k4tasks = nullptr;     // task list of k_schur_syrk4 (null: the 16x16x4 kernel, ZC > K4_PITCH)
     int *d_grp_v0 = nullptr, *d_chk_row0 = nullptr, *d_clist = nullptr, *d_clist_off = nullptr, *d_glist = nullptr, *d_glist_off = nullptr;
     double *d_obs_x = nullptr, *d_obs_y = nullptr;
     // device: parameters (current / candidate)
@@ -105,7 +106,7 @@ cvx_calib::~cvx_calib() {
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
-                    d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail};
+                    d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -194,6 +195,15 @@ int launch_schur(cvx_calib *h) {
     k.Z = h->d_Z; k.chk_row0 = h->d_chk_row0; k.slab = h->d_slab_tile;
     k.ZC = h->ZC; k.ZCp = h->ZCp; k.KB = h->KB; k.n_chunks = h->n_chunks; k.nb = h->nb; k.nblk = h->nblk; k.parts = h->parts;
     const int blocks = 8 * ((h->n_chunks + 7) / 8) * h->parts;
+    if (h->d_k4tasks) {
+        K4Args q;
+        q.Z = h->d_Z; q.chk_row0 = h->d_chk_row0; q.tasks = h->d_k4tasks; q.slab = h->d_slab_tile;
+        q.ZC = h->ZC; q.ZCp = K4_PITCH; q.KB = K4_KB; q.n_chunks = h->n_chunks; q.nb = h->nb; q.nblk = h->nblk; q.parts = h->parts;
+        CVX_HIP(hipFuncSetAttribute((const void *)k_schur_syrk4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+        hipLaunchKernelGGL(k_schur_syrk4, dim3(blocks), dim3(64 * K4_WAVES), h->k3_lds, h->stream, q);
+        CVX_HIP(hipGetLastError());
+        return CVX_OK;
+    }
     CVX_HIP(hipFuncSetAttribute((const void *)k_schur_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     hipLaunchKernelGGL(k_schur_syrk, dim3(blocks), dim3(64 * K3_WAVES), h->k3_lds, h->stream, k);
     CVX_HIP(hipGetLastError());
@@ -523,6 +533,12 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     while (h->KB > 4 && (h->KB * h->ZC > 6144 || 2 * (size_t)h->KB * h->ZCp * sizeof(double) > 128 * 1024)) h->KB -= 4;
     h->k3_lds = 2 * (size_t)h->KB * h->ZCp * sizeof(double);
     if (h->KB * h->ZC > 6144 || h->k3_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
+    // the register-tile form of the contraction (v_mfma_f64_4x4x4_4b) wherever its fixed LDS pitch holds a row
+    std::vector<K4Task> k4tasks;
+    if (h->ZC <= K4_PITCH) {
+        h->parts = k4_build_tasks(h->nb, k4tasks);
+        h->k3_lds = 2 * (size_t)K4_KB * K4_PITCH * sizeof(double) + 512;   // + slack: groups past nb are read, not used
+    }
     h->T = maxn <= 64 ? 64 : maxn <= 128 ? 128 : maxn <= 256 ? 256 : 512;
     const int W = h->T / 64;
     h->h_cam_of_view.assign(d->cam_of_view, d->cam_of_view + V);
@@ -589,6 +605,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(dev_upload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
     CVX_TRY(dev_upload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
     CVX_TRY(dev_upload(&h->d_chk_row0, chk_row0.data(), chk_row0.size(), s));
+    if (!k4tasks.empty()) CVX_TRY(dev_upload(&h->d_k4tasks, k4tasks.data(), k4tasks.size(), s));
     {
         std::vector<int> clist(h->n_chunks), clist_off(C + 1, 0);
         for (int q = 0; q < h->n_chunks; ++q) clist_off[chk_cam[q] + 1]++;

@@ -12,6 +12,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <vector>
+
 namespace cvxk {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -641,6 +644,217 @@ __global__ void __launch_bounds__(64 * K3_WAVES) k_schur_syrk(K3Args a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) out[(kq + 4 * q) * 16 + cq] = acc[i][q];
         }
+}
+
+// -----------------------------------------------------------------------------------------
+// K3, second form: the same contraction on v_mfma_f64_4x4x4_4b_f64, which this part issues at 16 cycles per
+// 512 flop (the 16x16x4 instruction: 103 cycles per 2048 flop, 62 % of that).  The instruction multiplies four
+// independent 4x4x4 blocks and pairs block b of A with block b of B only (lane i + 4b + 16k of A, j + 4b + 16k of
+// B, result in lane j + 4b + 16i), so an operand register loaded exactly like the 16x16x4 one -- lane (kq, cq) =
+// Z[4 ks + kq][16 g + cq] -- gives the four diagonal 4x4 blocks of the 16x16 product of groups (gA, gB); the
+// other twelve come from three DPP rotations of the B register by 4, 8, 12 lanes.  Operands would have to come
+// from LDS twice per four instructions that way, which is slower than 16x16x4; instead a wave keeps a register
+// tile of 4 x 4 groups (64 x 64 outputs, 64 accumulator registers): per k-step 4 A reads, 4 B reads and the B
+// rotations feed 64 instructions.
+// Tasks (one per wave, K4_WAVES per workgroup, `parts` workgroups per chunk, built by the host):
+//   FULL  tile (I, J), I < J: groups 4I..4I+3 x 4J..4J+3, those below nb
+//   DIAG  tile (I, I): the ten blocks pa <= qb; B operands are the A registers.  When nb = 1 mod 4 the last
+//         group would make a column of nearly empty tiles: its blocks (4I + pa, nb - 1) ride in four of the six
+//         unused accumulator slots of DIAG task I, and the corner block (nb - 1, nb - 1) in a fifth.
+// -----------------------------------------------------------------------------------------
+constexpr int K4_WAVES = 8;
+constexpr int K4_KB = 16;         // rows per stage
+constexpr int K4_PITCH = 400;     // LDS row pitch in doubles (16 mod 32: conflict-free operand reads); ZC <= 400
+
+struct K4Task {
+    int a0, b0;      // first column group of the A and B side
+    int nA, nB;      // valid groups (1..4)
+    int diag;        // 1: DIAG task (b0 == a0)
+    int edge;        // DIAG: column group riding in the free slots, or -1
+    int corner;      // DIAG: 1 if the block (edge, edge) rides too
+    int pad;
+};
+
+struct K4Args {
+    const double *Z;
+    const int *chk_row0;
+    const K4Task *tasks;   // [parts * K4_WAVES], nA = 0 marks an idle wave
+    double *slab;          // [n_chunks][nblk][256]
+    int ZC, ZCp, KB, n_chunks, nb, nblk, parts;
+};
+
+#define K4_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f64_4x4x4f64(A_, B_, C_, 0, 0, 0)
+
+// MODE 0: FULL 4 x 4 groups; 1: DIAG, 4 groups; 2: DIAG, 4 groups + the edge group: no branch in the k loop.
+// 3 / 4: FULL / DIAG with fewer than 4 x 4 groups (tiles at the border), one scalar branch per block.
+// The rotated B operands are read from LDS as such (lane (kq, cq) reads column 16 g + ((cq - 4r) & 15): the same
+// banks as the unrotated read), not made with DPP moves: every VALU instruction between the MFMAs costs them issue
+// slots (24 v_mov_dpp per k-step: 15 % of the kernel), LDS reads do not.  All LDS addresses are one VGPR per
+// (group, rotation), advanced once per stage; the k-step and the row pitch are immediates (K4_PITCH, K4_KB).
+template <int MODE>
+__device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chunk, double *lds) {
+    constexpr bool DIAG = (MODE == 1 || MODE == 2 || MODE == 4), GEN = MODE >= 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kq = lane >> 4, cq = lane & 15;
+    const int r0 = a.chk_row0[chunk], r1 = a.chk_row0[chunk + 1];
+    const int ZC = a.ZC, nb = a.nb;
+    const int nA = GEN ? t.nA : 4, nB = GEN ? t.nB : 4;
+    const bool has_edge = GEN ? (DIAG && t.edge >= 0) : (MODE == 2);
+    const bool has_corner = has_edge && t.corner;
+    // element offsets inside a stage buffer: A groups unrotated, B groups (or, DIAG, the A groups again) in four
+    // rotations, the edge group in four rotations
+    // (the groups of a side are consecutive: one address register per rotation, the group is an immediate; groups
+    // beyond nb are read too -- up to 48 columns past ZC, inside the pitch or the slack behind the buffers -- and
+    // their blocks skipped)
+    const int pA0 = kq * K4_PITCH + t.a0 * 16 + cq;
+    int pBr[4], pEr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pBr[r] = kq * K4_PITCH + t.b0 * 16 + ((cq - 4 * r) & 15);
+        pEr[r] = kq * K4_PITCH + (has_edge ? t.edge : 0) * 16 + ((cq - 4 * r) & 15);
+    }
+    double acc[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+
+    // staging: K4_KB rows of ZC doubles per stage; 32 threads per row, 16 bytes each, six column slices
+    const int halfc = ZC >> 1;
+    constexpr int NLD = (K4_PITCH / 2 + 31) / 32;
+    const int srow = tid >> 5, sc = tid & 31;
+    const int nstages = (r1 - r0 + K4_KB - 1) / K4_KB;
+    double2 st[NLD];
+    auto fetch = [&](int s) {
+        const int grow = r0 + s * K4_KB + srow;
+        const double2 *g = (const double2 *)(a.Z + (size_t)grow * ZC) + sc;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            st[i] = double2{0.0, 0.0};
+            if (sc + 32 * i < halfc && grow < r1) st[i] = g[32 * i];
+        }
+    };
+    auto stash = [&](int buf) {
+        double2 *dst = (double2 *)(lds + (size_t)buf * K4_KB * K4_PITCH + srow * K4_PITCH) + sc;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (sc + 32 * i < halfc) dst[32 * i] = st[i];
+    };
+    auto kstep = [&](const double *p) {     // p = stage buffer + 4 ks rows
+        double av[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = p[pA0 + 16 * i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (DIAG && r == 0) ? av[j] : p[pBr[r] + 16 * j];
+#pragma unroll
+            for (int i = 0; i < (DIAG ? j + 1 : 4); ++i)
+                if (!GEN || (i < nA && j < nB)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) K4_MFMA(av[i], bv[r], acc[i][j][r]);
+                }
+        }
+        if (DIAG && has_edge) {
+            double ev[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ev[r] = p[pEr[r]];
+            // free slots (1,0) (2,0) (2,1) (3,0): blocks (a0 + 0..3, edge); (3,1): the corner block
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                K4_MFMA(av[0], ev[r], acc[1][0][r]);
+                if (!GEN || nA > 1) K4_MFMA(av[1], ev[r], acc[2][0][r]);
+                if (!GEN || nA > 2) K4_MFMA(av[2], ev[r], acc[2][1][r]);
+                if (!GEN || nA > 3) K4_MFMA(av[3], ev[r], acc[3][0][r]);
+            }
+            if (has_corner) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) K4_MFMA(ev[0], ev[r], acc[3][1][r]);
+            }
+        }
+    };
+    if (nstages > 0) { fetch(0); stash(0); }
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+#ifndef K4_EXP_NOSTAGE
+        if (s + 1 < nstages) fetch(s + 1);
+#endif
+        const double *src = lds + (size_t)(s & 1) * K4_KB * K4_PITCH;
+        if (!GEN || nA > 0) {
+#pragma unroll
+            for (int ks = 0; ks < K4_KB; ks += 4) kstep(src + ks * K4_PITCH);
+        }
+#ifndef K4_EXP_NOSTAGE
+        if (s + 1 < nstages) stash((s + 1) & 1);
+        __syncthreads();
+#endif
+    }
+    if (nA <= 0) return;
+    // accumulator r of block (gA, gB), lane l: row 4b + i, column 4((b - r) & 3) + j with i = l >> 4, b = (l >> 2) & 3,
+    // j = l & 3 (the rotation by 4r hands block b the B block b - r)
+    const int li = lane >> 4, lb = (lane >> 2) & 3, lj = lane & 3;
+    auto put = [&](int gA, int gB, const double (&v)[4]) {
+        const int q = gA * nb - gA * (gA - 1) / 2 + (gB - gA);
+        double *out = a.slab + ((size_t)chunk * a.nblk + q) * 256 + (4 * lb + li) * 16 + lj;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[4 * ((lb - r) & 3)] = v[r];
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = DIAG ? i : 0; j < 4; ++j)
+            if (i < nA && j < nB) put(t.a0 + i, t.b0 + j, acc[i][j]);
+    if (DIAG && has_edge) {
+        put(t.a0, t.edge, acc[1][0]);
+        if (nA > 1) put(t.a0 + 1, t.edge, acc[2][0]);
+        if (nA > 2) put(t.a0 + 2, t.edge, acc[2][1]);
+        if (nA > 3) put(t.a0 + 3, t.edge, acc[3][0]);
+        if (has_corner) put(t.edge, t.edge, acc[3][1]);
+    }
+}
+
+__global__ void __launch_bounds__(64 * K4_WAVES, 2) k_schur_syrk4(K4Args a) {
+    extern __shared__ double lds[];      // [2][KB][ZCp]
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int part = slot % a.parts, chunk = (slot / a.parts) * 8 + xcd;
+    if (chunk >= a.n_chunks) return;
+    K4Task t = a.tasks[part * K4_WAVES + (threadIdx.x >> 6)];
+    // wave-uniform: keep the task in scalar registers, so that the per-block tests are scalar branches
+    t.a0 = __builtin_amdgcn_readfirstlane(t.a0); t.b0 = __builtin_amdgcn_readfirstlane(t.b0);
+    t.nA = __builtin_amdgcn_readfirstlane(t.nA); t.nB = __builtin_amdgcn_readfirstlane(t.nB);
+    t.diag = __builtin_amdgcn_readfirstlane(t.diag); t.edge = __builtin_amdgcn_readfirstlane(t.edge);
+    t.corner = __builtin_amdgcn_readfirstlane(t.corner);
+    const bool whole = t.nA == 4 && t.nB == 4;
+    if (!t.diag) {
+        if (whole) k4_body<0>(a, t, chunk, lds); else k4_body<3>(a, t, chunk, lds);
+    } else if (whole) {
+        if (t.edge >= 0) k4_body<2>(a, t, chunk, lds); else k4_body<1>(a, t, chunk, lds);
+    } else {
+        k4_body<4>(a, t, chunk, lds);
+    }
+}
+
+// host: the task list of k_schur_syrk4 for nb column groups, padded to a multiple of K4_WAVES with idle entries;
+// returns the number of parts
+inline int k4_build_tasks(int nb, std::vector<K4Task> &tasks) {
+    tasks.clear();
+    const bool merge = (nb % 4 == 1) && nb > 4;     // the last group rides in the DIAG tasks
+    const int ng = merge ? nb - 1 : nb, TI = (ng + 3) / 4;
+    // FULL tasks first: every part then holds tasks of the same (largest) size
+    for (int I = 0; I < TI; ++I)
+        for (int J = I + 1; J < TI; ++J)
+            tasks.push_back(K4Task{4 * I, 4 * J, std::min(4, ng - 4 * I), std::min(4, ng - 4 * J), 0, -1, 0, 0});
+    for (int I = 0; I < TI; ++I) {
+        const int n = std::min(4, ng - 4 * I);
+        tasks.push_back(K4Task{4 * I, 4 * I, n, n, 1, merge ? nb - 1 : -1, (merge && I == TI - 1) ? 1 : 0, 0});
+    }
+    const int parts = ((int)tasks.size() + K4_WAVES - 1) / K4_WAVES;
+    while ((int)tasks.size() < parts * K4_WAVES) tasks.push_back(K4Task{0, 0, 0, 0, 0, -1, 0, 0});
+    return parts;
 }
 
 // -----------------------------------------------------------------------------------------
