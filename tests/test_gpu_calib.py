@@ -17,6 +17,9 @@ CASES = {
     "config1_fixed_points": dict(spec=(1, 20, 9, 6, 20260001), ragged=0, fix={"fix_points": True}),
     "two_cameras_ragged": dict(spec=(2, 7, 12, 9, 11), ragged=4, fix={}),
     "three_cameras_free_k3_big_board": dict(spec=(3, 5, 20, 15, 12), ragged=3, fix={"fix_k3": False}),
+    # 5 x 4 board: ZC = 80 = 5 column groups, the shape (nb = 1 mod 4) where the Schur kernel's diagonal tasks carry
+    # the last group in their free accumulators (as nb = 21 at config 4 does)
+    "five_column_groups": dict(spec=(2, 8, 5, 4, 17), ragged=0, fix={}),
     "fixed_intrinsics": dict(spec=(1, 6, 9, 6, 13), ragged=0, fix={"fix_intrinsics": True}),
     "all_shared_fixed": dict(spec=(2, 4, 9, 6, 14), ragged=2, fix={"fix_intrinsics": True, "fix_points": True}),
     # a single planar view cannot determine the intrinsics (the run is chaotic): pose-only problem
@@ -133,7 +136,9 @@ def test_damped_linear_step_matches_oracle(orc, case):
     g.close()
 
 
-@pytest.mark.parametrize("case", list(CASES))
+# (the 20-point board is there for the shape of its reduced system -- checked entry by entry above; its solve is
+# flat to rounding level from the fourth iteration on, where the per-iteration 1e-12 figure has no meaning)
+@pytest.mark.parametrize("case", [c for c in CASES if c != "five_column_groups"])
 @pytest.mark.parametrize("kind", ["refine", "levmar"])
 def test_full_solve_follows_oracle(orc, case, kind):
     d, g, o = make(case, orc)
