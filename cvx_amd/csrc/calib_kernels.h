@@ -799,6 +799,9 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
     auto put = [&](int gA, int gB, const double (&v)[4]) {
         const int q = gA * nb - gA * (gA - 1) / 2 + (gB - gA);
         double *out = a.slab + ((size_t)chunk * a.nblk + q) * 256 + (4 * lb + li) * 16 + lj;
+#ifdef K4_EXP_NOSTORE
+        if (v[0] == 1.2345e-300)
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[4 * ((lb - r) & 3)] = v[r];
     };
@@ -891,20 +894,26 @@ __device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, 
     if (j.wide) {
         // short lists (the Schur tiles: one entry per chunk of the camera): 2 KB coalesced rows, no LDS, sixteen
         // independent loads in flight per thread
-        const int e = bx * 256 + threadIdx.x;
+        // (two adjacent outputs per thread: 16-byte loads, 1 KB per wave instruction; n_out is a multiple of 256)
+        const int e = 2 * (bx * 256 + threadIdx.x);
         if (e >= j.n_out) return;
         const int q0 = j.list_off[c], q1 = j.list_off[c + 1];
-        double s = 0.0;
+        double2 s = {0.0, 0.0};
         int q = q0;
         for (; q + 16 <= q1; q += 16) {
-            double v[16];
+            double2 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = j.src[(size_t)j.list[q + u] * j.stride + e];
-            s += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-                 (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+            for (int u = 0; u < 16; ++u) v[u] = *(const double2 *)(j.src + (size_t)j.list[q + u] * j.stride + e);
+            s.x += (((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x))) +
+                   (((v[8].x + v[9].x) + (v[10].x + v[11].x)) + ((v[12].x + v[13].x) + (v[14].x + v[15].x)));
+            s.y += (((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y))) +
+                   (((v[8].y + v[9].y) + (v[10].y + v[11].y)) + ((v[12].y + v[13].y) + (v[14].y + v[15].y)));
         }
-        for (; q < q1; ++q) s += j.src[(size_t)j.list[q] * j.stride + e];
-        j.dst[(size_t)c * j.n_out + e] = s;
+        for (; q < q1; ++q) {
+            const double2 v = *(const double2 *)(j.src + (size_t)j.list[q] * j.stride + e);
+            s.x += v.x; s.y += v.y;
+        }
+        *(double2 *)(j.dst + (size_t)c * j.n_out + e) = s;
         return;
     }
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
