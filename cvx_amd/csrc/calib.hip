@@ -59,6 +59,7 @@ struct cvx_calib {
     std::vector<int> h_cam_of_view, h_view_off;
     // device: static
     int *d_view_off = nullptr, *d_cam_of_view = nullptr, *d_point_id = nullptr, *d_view_id = nullptr;
+    bool A_ready = false;            // the last linearisation wrote the damped matrix A itself (one rank)
     K4Task *d_k4tasks = nullptr;     // task list of k_schur_syrk4 (null: the 16x16x4 kernel, ZC > K4_PITCH)
     int *d_grp_v0 = nullptr, *d_chk_row0 = nullptr, *d_clist = nullptr, *d_clist_off = nullptr, *d_glist = nullptr, *d_glist_off = nullptr;
     double *d_obs_x = nullptr, *d_obs_y = nullptr;
@@ -258,7 +259,12 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         s.ns = h->ns; s.C = h->C; s.P = h->P; s.ncf = h->ncf; s.fix_k3 = h->fix_k3; s.pts_free = h->pts_free;
         s.ZC = h->ZC; s.camcol0 = h->camcol0; s.ycol = h->ycol; s.nb = h->nb; s.nblk = h->nblk;
         s.E = h->d_E;
-        const long long n = (long long)h->ns * h->ns + h->ns;
+        // one rank: nothing lies between the assembly and the damped matrix of the solve, so it is made here
+        h->A_ready = !init_mode && h->nranks == 1;
+        s.A = h->A_ready ? h->d_A : nullptr; s.Ds = h->d_Ds; s.s2 = h->d_s2sh; s.npad = h->npad;
+        s.inv_radius = d.inv_radius; s.mu = d.mu; s.min_diag = d.min_diag; s.max_diag = d.max_diag;
+        const long long pitch = h->A_ready ? h->npad : h->ns;
+        const long long n = pitch * pitch + h->ns;
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, s);
         CVX_HIP(hipGetLastError());
     }
@@ -374,7 +380,8 @@ private:
             da.inv_radius = d.inv_radius; da.mu = d.mu; da.min_diag = d.min_diag; da.max_diag = d.max_diag;
             da.A = h->d_A; da.Ds = h->d_Ds;
             const long long tot = (long long)h->npad * h->npad;
-            hipLaunchKernelGGL(cvxs::k_damp_prepare, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, da);
+            if (!h->A_ready)
+                hipLaunchKernelGGL(cvxs::k_damp_prepare, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, da);
             if (want_S) {
                 h->h_A.resize((size_t)tot);
                 CVX_HIP(hipMemcpyAsync(h->h_A.data(), h->d_A, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -986,6 +986,12 @@ struct AsmArgs {
     const double *Tt, *Tpt, *Gcam;
     int ns, C, P, ncf, fix_k3, pts_free, ZC, camcol0, ycol, nb, nblk;
     double *E;
+    // single-rank runs: the damped, padded matrix of the reduced solve is written in the same pass (what
+    // cvxs::k_damp_prepare makes from E when an exchange step lies between); A == nullptr: E only
+    double *A, *Ds;
+    const double *s2;
+    int npad;
+    double inv_radius, mu, min_diag, max_diag;
 };
 
 struct SharedIdx {
@@ -1026,13 +1032,22 @@ __device__ __forceinline__ double tile_sum(const AsmArgs &a, int cam, int zi, in
     return z;
 }
 
+// Thread grid: pitch x pitch matrix entries, then ns vector entries; pitch = ns, or npad when A is written too
+// (the entries outside ns x ns are then A's right-hand-side row, its 1e300 pivot and the identity padding).
 __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nn = (long long)a.ns * a.ns;
-    if (t >= nn + a.ns) return;
+    const int pitch = a.A ? a.npad : a.ns;
+    const long long mm = (long long)pitch * pitch;
+    if (t >= mm + a.ns) return;
     const int sym6[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
-    if (t < nn) {
-        const int i = (int)(t / a.ns), j = (int)(t % a.ns);
+    if (t < mm) {
+        const int i = (int)(t / pitch), j = (int)(t % pitch);
+        if (i >= a.ns || j >= a.ns) {
+            // row ns below column ns is the right-hand side (the vector threads write it); the rest is constant
+            if (!(i == a.ns && j < a.ns)) a.A[t] = (i == j) ? (i == a.ns ? 1e300 : 1.0) : 0.0;
+            return;
+        }
         const SharedIdx si = shared_index(a, i), sj = shared_index(a, j);
         double u = 0.0, z = 0.0;
         if (si.is_cam && sj.is_cam) {
@@ -1051,9 +1066,22 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
                 for (int c = 0; c < a.C; ++c) u += a.Tpt[((size_t)c * a.P + si.p) * PT_ACC + 27 + sym6[si.b * 3 + sj.b]];
             z = tile_sum(a, -1, si.zcol, sj.zcol);
         }
-        a.E[t] = u - z;
+        const double e = u - z;
+        a.E[(size_t)i * a.ns + j] = e;
+        if (a.A) {
+            double v = e;
+            if (i == j) {       // D_i = clamp(s_i^2 U_ii, min, max) / (radius s_i^2) + mu, as k_damp_prepare
+                const double s2 = a.s2[i];
+                double c = s2 * u;
+                c = fmin(fmax(c, a.min_diag), a.max_diag);
+                c = c * a.inv_radius / s2 + a.mu;
+                a.Ds[i] = c;
+                v += c;
+            }
+            a.A[t] = v;
+        }
     } else {
-        const int i = (int)(t - nn);
+        const int i = (int)(t - mm);
         const SharedIdx si = shared_index(a, i);
         double g = 0.0, d = 0.0;
         if (si.is_cam) {
@@ -1070,6 +1098,7 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
         a.E[nn + i] = g - z;
         a.E[nn + a.ns + i] = g;
         a.E[nn + 2 * a.ns + i] = d;
+        if (a.A) a.A[(size_t)a.ns * a.npad + i] = -(g - z);
     }
 }
 
