@@ -1121,10 +1121,13 @@ __global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z,
     const double *ds = ds_emb + (size_t)cam_of_view[v] * ZC;
     const double *Zv = Z + (size_t)6 * v * ZC;
     double t[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = lane; c < ZC; c += 64) {
-        const double d = ds[c];
+    for (int c = 2 * lane; c < ZC; c += 128) {       // ZC is a multiple of 16: 16-byte loads, 1 KB per wave instruction
+        const double2 d = *(const double2 *)(ds + c);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) t[i] += Zv[(size_t)i * ZC + c] * d;
+        for (int i = 0; i < 6; ++i) {
+            const double2 z = *(const double2 *)(Zv + (size_t)i * ZC + c);
+            t[i] += z.x * d.x + z.y * d.y;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -1182,10 +1185,13 @@ __global__ void __launch_bounds__(256) k_backsubst_cost(const double *__restrict
     // the view's observations do not depend on the step: fetch them first
     const int o0 = view_off[v], o1 = view_off[v + 1];
     double t[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = lane; c < ZC; c += 64) {
-        const double d = ds[c];
+    for (int c = 2 * lane; c < ZC; c += 128) {       // ZC is a multiple of 16: 16-byte loads, 1 KB per wave instruction
+        const double2 d = *(const double2 *)(ds + c);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) t[i] += Zv[(size_t)i * ZC + c] * d;
+        for (int i = 0; i < 6; ++i) {
+            const double2 z = *(const double2 *)(Zv + (size_t)i * ZC + c);
+            t[i] += z.x * d.x + z.y * d.y;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
