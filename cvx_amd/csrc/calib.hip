@@ -240,7 +240,7 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         auto add = [&](const double *src, int n_out, const int *list, const int *off, double *dst, bool wide = false) {
             SumJob &j = ra.job[ra.njobs++];
             j.wide = wide ? 1 : 0;
-            j.src = src; j.stride = (size_t)n_out; j.n_out = n_out; j.blocks_x = wide ? (n_out + 511) / 512 : (n_out + 63) / 64;
+            j.src = src; j.stride = (size_t)n_out; j.n_out = n_out; j.blocks_x = wide ? (n_out + 511) / 512 : (n_out + 127) / 128;   // n_out is even (36 per point, 256 per tile)
             j.list = list; j.list_off = off; j.dst = dst;
         };
         if (schur) add(h->d_slab_tile, h->nblk * 256, h->d_clist, h->d_clist_off, h->d_Tt, true);

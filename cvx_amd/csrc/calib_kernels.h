@@ -890,7 +890,7 @@ struct ReduceArgs {
     int *fail;      // factorisation flag of the reduced solve, cleared here for this linear step
 };
 
-__device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, double (*part)[64]) {
+__device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, double (*part)[128]) {
     if (j.wide) {
         // short lists (the Schur tiles: one entry per chunk of the camera): 2 KB coalesced rows, no LDS, sixteen
         // independent loads in flight per thread
@@ -916,31 +916,41 @@ __device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, 
         *(double2 *)(j.dst + (size_t)c * j.n_out + e) = s;
         return;
     }
+    // 128 outputs (two per lane, 16-byte loads; n_out is even) x 4 slices of the list
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = bx * 64 + lane;
+    const int e = bx * 128 + 2 * lane;
     const int q0 = j.list_off[c], q1 = j.list_off[c + 1];
     const int per = (q1 - q0 + 3) >> 2;
     const int a0 = q0 + sl * per, a1 = min(q1, a0 + per);
-    double s = 0.0;
+    double2 s = {0.0, 0.0};
     if (e < j.n_out) {
         int q = a0;
         for (; q + 8 <= a1; q += 8) {       // eight independent loads in flight
-            double v[8];
+            double2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = j.src[(size_t)j.list[q + u] * j.stride + e];
-            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            for (int u = 0; u < 8; ++u) v[u] = *(const double2 *)(j.src + (size_t)j.list[q + u] * j.stride + e);
+            s.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+            s.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
         }
-        for (; q < a1; ++q) s += j.src[(size_t)j.list[q] * j.stride + e];
+        for (; q < a1; ++q) {
+            const double2 v = *(const double2 *)(j.src + (size_t)j.list[q] * j.stride + e);
+            s.x += v.x; s.y += v.y;
+        }
     }
-    part[sl][lane] = s;
+    part[sl][2 * lane] = s.x; part[sl][2 * lane + 1] = s.y;
     __syncthreads();
-    if (sl == 0 && e < j.n_out) j.dst[(size_t)c * j.n_out + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (sl == 0 && e < j.n_out) {
+        double2 r;
+        r.x = (part[0][2 * lane] + part[1][2 * lane]) + (part[2][2 * lane] + part[3][2 * lane]);
+        r.y = (part[0][2 * lane + 1] + part[1][2 * lane + 1]) + (part[2][2 * lane + 1] + part[3][2 * lane + 1]);
+        *(double2 *)(j.dst + (size_t)c * j.n_out + e) = r;
+    }
 }
 
 // all slab sums of one linearisation in one launch: blocks [0, sum_j blocks_x_j * C) do the jobs,
 // the last block the scalars
 __global__ void __launch_bounds__(256) k_reduce_all(ReduceArgs a) {
-    __shared__ double part[4][64];
+    __shared__ double part[4][128];
     int b = blockIdx.x;
     for (int ji = 0; ji < a.njobs; ++ji) {
         const int nb = a.job[ji].blocks_x * a.C;
