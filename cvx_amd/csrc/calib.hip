@@ -881,3 +881,10 @@ extern "C" int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]) {
     out[5] = h->T; out[6] = 6LL * h->V; out[7] = 0;
     return CVX_OK;
 }
+
+#ifdef K2_PROF
+extern "C" int cvx_calib_debug_group_scalars(cvx_calib *h, double *out) {
+    CVX_HIP(hipMemcpy(out, h->d_grp_scal, sizeof(double) * 4 * h->n_groups, hipMemcpyDeviceToHost));
+    return h->n_groups;
+}
+#endif

@@ -291,7 +291,11 @@ __device__ __forceinline__ bool chol6_factor(double (&A)[21]) {
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= A[TRI(j, k)] * A[TRI(j, k)];
         ok = ok && (s > 0.0) && (s < 1.7e308);
-        const double ri = ok ? rsqrt(s) : 0.0;
+        // 1 / sqrt(s): hardware estimate and one third-order Newton step (error ~ e^3, below the last bit); the
+        // library rsqrt() is six times this dependent chain, and the six pivots are sequential
+        const double y0 = __builtin_amdgcn_rsq(s);
+        const double e = fma(-s * y0, y0, 1.0);
+        const double ri = ok ? fma(y0 * e, fma(e, 0.375, 0.5), y0) : 0.0;
         A[TRI(j, j)] = ri;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
@@ -369,7 +373,16 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
     }
     __syncthreads();
 
+#ifdef K2_PROF
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp;
+#define K2_STAMP(i) do { const long long tn = clock64(); ph[i] += tn - tp; tp = tn; } while (0)
+#else
+#define K2_STAMP(i) do {} while (0)
+#endif
     for (int v = v0; v < v1; ++v) {
+#ifdef K2_PROF
+        tp = clock64();
+#endif
         const int base = a.view_off[v];
         const int n = a.view_off[v + 1] - base;
         const double *rt = a.rt + (size_t)v * RT_STRIDE;
@@ -389,6 +402,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) Jx[i] = 0.0;
         }
+        K2_STAMP(0);
         // ---- per-point accumulators (unique point ids inside a view: plain read-modify-write) ----
         if (active && a.pts_free) {
             double inc[PT_ACC];
@@ -416,6 +430,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
                     if (i >= 27 || a.cam_free) pa[i] += inc[i];
             }
         }
+        K2_STAMP(1);
         // ---- Gram of the staged rows on the matrix cores ----
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -439,6 +454,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) tiles[wave * 256 + ((lane >> 4) + 4 * i) * 16 + (lane & 15)] = acc[i];
         acc_tot += acc;
+        K2_STAMP(2);
         __syncthreads();
         for (int e = tid; e < 256; e += T) {
             double s = tiles[e];
@@ -448,6 +464,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
         }
         __syncthreads();
 
+        K2_STAMP(3);
         // ---- pose block: damping, factor, inverse (every lane redundantly, operands broadcast) ----
         double A[21], gvv[6], Dd[6];
 #pragma unroll
@@ -480,6 +497,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
         if (MODE == 0) {
             const bool ok = chol6_factor(A);
             if (!ok) nbad = 1.0;
+            K2_STAMP(4);
             double *Zv = a.Z + (size_t)6 * v * a.ZC;
             // point columns: Z[.][3 pid + b] = L^-1 (Jp^T Jx)[.][b]
             if (active && a.pts_free) {
@@ -493,7 +511,8 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
                     for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + 3 * pid + b] = w[i];
                 }
             }
-            // camera columns (lanes 0..8), reduced-gradient column (lane 9), per-view records (lane 10)
+            K2_STAMP(6);
+            // camera columns (lanes 0..8), reduced-gradient column (lane 9)
             if (tid < 10) {
                 const bool isy = (tid == 9);
                 if (isy || a.cam_free) {
@@ -505,7 +524,10 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + col] = w[i];
                 }
-            } else if (tid == 10) {
+            }
+            // per-view records: one lane of the LAST wave (which has nothing else to do here), so that the 33
+            // single-lane stores do not sit behind the camera columns on wave 0's path to the next barrier
+            if (tid == T - 1) {
 #pragma unroll
                 for (int i = 0; i < 21; ++i) a.Lfac[(size_t)21 * v + i] = A[i];
 #pragma unroll
@@ -515,6 +537,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
                 }
             }
         }
+        K2_STAMP(5);
     }
     // ---- flush the group's accumulators ----
     double *sp = a.slab_pt + (size_t)g * a.P * PT_ACC;
@@ -542,7 +565,11 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
         a.grp_scal[4 * g + 0] = gmax;
         a.grp_scal[4 * g + 1] = dmax;
         a.grp_scal[4 * g + 2] = nbad;
+#ifdef K2_PROF
+        a.grp_scal[4 * g + 3] = (double)ph[g % 8];
+#else
         a.grp_scal[4 * g + 3] = 0.0;
+#endif
     }
 }
 
