@@ -73,6 +73,8 @@ struct cvx_calib {
     double *d_slab_pt = nullptr, *d_slab_cam = nullptr, *d_grp_scal = nullptr, *d_slab_tile = nullptr;
     double *d_Tpt = nullptr, *d_Tt = nullptr, *d_Gcam = nullptr;
     double *d_E = nullptr, *h_E = nullptr;
+    double *d_X = nullptr;           // ranks > 1: the exchanged buffer (packed lower triangle of S + the tail of E); h_E stages it
+    size_t X_count = 0, X_tail = 0;
     size_t E_count = 0, E_scal = 0;
     double *d_ds_emb = nullptr, *h_ds_emb = nullptr, *d_dposes = nullptr, *d_out_view = nullptr;
     double *d_cost_partial = nullptr, *d_cost_view = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
@@ -107,7 +109,7 @@ cvx_calib::~cvx_calib() {
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
-                    d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks};
+                    d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -263,22 +265,30 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         h->A_ready = !init_mode && h->nranks == 1;
         s.A = h->A_ready ? h->d_A : nullptr; s.Ds = h->d_Ds; s.s2 = h->d_s2sh; s.npad = h->npad;
         s.inv_radius = d.inv_radius; s.mu = d.mu; s.min_diag = d.min_diag; s.max_diag = d.max_diag;
+        s.X = (h->nranks > 1) ? h->d_X : nullptr; s.n_scal = 2 + 2 * h->nranks;
         const long long pitch = h->A_ready ? h->npad : h->ns;
         const long long n = pitch * pitch + h->ns;
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, s);
         CVX_HIP(hipGetLastError());
     }
     ph_end(h, PH_ASSEMBLE);
-    // exchange step (view-sharded runs): one all-reduce of [S | gred | gs | diagU | scalars]
+    // exchange step (view-sharded runs): one all-reduce of X = [lower triangle of S | gred | gs | diagU | scalars];
+    // the reduced tail then goes back behind E's (local) S, where the solve and the host read it
     if (h->nranks > 1 && h->xfn) {
-        if (h->xdev) {
-            if (h->xfn(h->xctx, h->d_E, h->E_count, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
-        } else {
-            CVX_HIP(hipMemcpyAsync(h->h_E, h->d_E, h->E_count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            CVX_HIP(hipStreamSynchronize(h->stream));
-            if (h->xfn(h->xctx, h->h_E, h->E_count, 0, nullptr)) return CVX_ERR_EXCHANGE;
-            CVX_HIP(hipMemcpyAsync(h->d_E, h->h_E, h->E_count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (h->ns == 0) {
+            // no shared unknowns: X is the scalars only and k_assemble did not run
+            CVX_HIP(hipMemcpyAsync(h->d_X, h->d_E, h->X_count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         }
+        if (h->xdev) {
+            if (h->xfn(h->xctx, h->d_X, h->X_count, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
+        } else {
+            CVX_HIP(hipMemcpyAsync(h->h_E, h->d_X, h->X_count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            CVX_HIP(hipStreamSynchronize(h->stream));
+            if (h->xfn(h->xctx, h->h_E, h->X_count, 0, nullptr)) return CVX_ERR_EXCHANGE;
+            CVX_HIP(hipMemcpyAsync(h->d_X, h->h_E, h->X_count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
+        CVX_HIP(hipMemcpyAsync(h->d_E + (size_t)h->ns * h->ns, h->d_X + h->X_tail, (h->X_count - h->X_tail) * sizeof(double),
+                               hipMemcpyDeviceToDevice, h->stream));
     }
     return CVX_OK;
 }
@@ -376,7 +386,7 @@ private:
         ph_begin(h, PH_SOLVE);
         if (ns > 0) {
             cvxs::DampArgs da;
-            da.E = h->d_E; da.s2 = h->d_s2sh; da.n = ns; da.npad = h->npad;
+            da.E = h->d_E; da.Sp = (h->nranks > 1) ? h->d_X : nullptr; da.s2 = h->d_s2sh; da.n = ns; da.npad = h->npad;
             da.inv_radius = d.inv_radius; da.mu = d.mu; da.min_diag = d.min_diag; da.max_diag = d.max_diag;
             da.A = h->d_A; da.Ds = h->d_Ds;
             const long long tot = (long long)h->npad * h->npad;
@@ -475,6 +485,14 @@ int alloc_exchange(cvx_calib *h) {
     if (st) return st;
     CVX_HIP(hipMemsetAsync(h->d_E, 0, h->E_count * sizeof(double), h->stream));
     CVX_HIP(hipHostMalloc((void **)&h->h_E, h->E_count * sizeof(double), hipHostMallocDefault));
+    if (h->d_X) { (void)hipFree(h->d_X); h->d_X = nullptr; }
+    h->X_tail = (size_t)h->ns * (h->ns + 1) / 2;
+    h->X_count = h->X_tail + (h->E_count - (size_t)h->ns * h->ns);
+    if (h->nranks > 1) {
+        st = dev_alloc(&h->d_X, h->X_count);
+        if (st) return st;
+        CVX_HIP(hipMemsetAsync(h->d_X, 0, h->X_count * sizeof(double), h->stream));
+    }
     return CVX_OK;
 }
 

@@ -1029,6 +1029,10 @@ struct AsmArgs {
     const double *s2;
     int npad;
     double inv_radius, mu, min_diag, max_diag;
+    // view-sharded runs: what the ranks exchange, X = [lower triangle of S, packed i(i+1)/2 + j | gred | gs | diagU |
+    // scalars] -- half of E; X == nullptr otherwise
+    double *X;
+    int n_scal;
 };
 
 struct SharedIdx {
@@ -1105,6 +1109,7 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
         }
         const double e = u - z;
         a.E[(size_t)i * a.ns + j] = e;
+        if (a.X && i >= j) a.X[(size_t)i * (i + 1) / 2 + j] = e;
         if (a.A) {
             double v = e;
             if (i == j) {       // D_i = clamp(s_i^2 U_ii, min, max) / (radius s_i^2) + mu, as k_damp_prepare
@@ -1136,6 +1141,12 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
         a.E[nn + a.ns + i] = g;
         a.E[nn + 2 * a.ns + i] = d;
         if (a.A) a.A[(size_t)a.ns * a.npad + i] = -(g - z);
+        if (a.X) {
+            double *xt = a.X + (size_t)a.ns * (a.ns + 1) / 2;
+            xt[i] = g - z; xt[a.ns + i] = g; xt[2 * a.ns + i] = d;
+            if (i == 0)     // the scalars of the linearisation, left behind the vectors of E by k_reduce_all
+                for (int q = 0; q < a.n_scal; ++q) xt[3 * a.ns + q] = a.E[nn + 3 * a.ns + q];
+        }
     }
 }
 

@@ -25,6 +25,7 @@ constexpr int TB = 32;
 // -----------------------------------------------------------------------------------------
 struct DampArgs {
     const double *E;    // S (n*n) | gred (n) | gs (n) | diagU (n)
+    const double *Sp;   // view-sharded runs: the all-reduced lower triangle of S, packed i(i+1)/2 + j (else nullptr)
     const double *s2;   // Jacobi scales squared
     int n, npad;
     double inv_radius, mu, min_diag, max_diag;
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(256) k_damp_prepare(DampArgs a) {
     const int n = a.n;
     double v = 0.0;
     if (i < n && j < n) {
-        v = a.E[(size_t)i * n + j];
+        v = a.Sp ? (i >= j ? a.Sp[(size_t)i * (i + 1) / 2 + j] : a.Sp[(size_t)j * (j + 1) / 2 + i]) : a.E[(size_t)i * n + j];
         if (i == j) {
             const double s2 = a.s2[i];
             double c = s2 * a.E[(size_t)n * n + 2 * n + i];

@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(dintr, 0, 9 * C * 8)); CK(hipMemset(dpts, 0, 3 * P * 8));
     CK(hipMalloc(&demb, (size_t)C * ZC * 8)); CK(hipMalloc(&ddelta, n * 8)); CK(hipMalloc(&dR, 16 * 8)); CK(hipMalloc(&dfail, 4));
     hipEvent_t ev[4]; for (int i = 0; i < 4; ++i) CK(hipEventCreate(&ev[i]));
-    cvxs::DampArgs da{dE, ds2, n, npad, 1e-4, 0.0, 1e-6, 1e32, dA, dDs};
+    cvxs::DampArgs da{dE, nullptr, ds2, n, npad, 1e-4, 0.0, 1e-6, 1e32, dA, dDs};
     cvxs::FinishArgs f{};
     f.L = dL; f.ld = npad; f.n = n; f.npad = npad; f.E = dE; f.E_scal = (long long)n * n + 3 * n; f.nranks = 1; f.Ds = dDs; f.fail = dfail;
     f.C = C; f.P = P; f.ncf = ncf; f.fix_k3 = 1; f.cam_free = 1; f.pts_free = 1; f.ZC = ZC; f.camcol0 = camcol0; f.ycol = ycol;
