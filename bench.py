@@ -49,7 +49,12 @@ class _DevBuf:
 
 def make_hook(torch, dist, capi):
     """cvx_allreduce_fn on torch.distributed (backend nccl = RCCL over xGMI)."""
+    calls = [0]
+
     def hook(ctx, buf, count, on_device, stream):
+        calls[0] += 1
+        if os.environ.get("CVX_BENCH_TRACE_HOOK") == "1":
+            sys.stderr.write("[rank %s] exchange %d: %d doubles\n" % (os.environ.get("RANK"), calls[0], count)); sys.stderr.flush()
         try:
             if on_device:
                 t = torch.as_tensor(_DevBuf(C.cast(buf, C.c_void_p).value, count), device="cuda")
@@ -232,10 +237,22 @@ def main():
 
     if capi.lib().cvx_device_count() < 1:
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
+    # rehearsal on a one-GPU box (not a measurement): CVX_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges
+    # over gloo, so that the N > 1 code path -- sharding, device-buffer hook, packed exchange -- runs end to end
+    rehearsal = world > 1 and os.environ.get("CVX_BENCH_REHEARSAL") == "1"
+
+    def trace(msg):
+        if rehearsal:
+            sys.stderr.write("[rank %d] %s\n" % (rank, msg)); sys.stderr.flush()
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- this rank's shard of the global problem: its own 10 000 views, the shared block replicated ----
     d = cvx_amd.synth_calib(CAMERAS, VIEWS_PER_CAMERA, BOARD_W, BOARD_H, SEED + 1000 * rank)
@@ -253,7 +270,9 @@ def main():
         hook = None
         if world > 1:
             hook = make_hook(torch, dist, capi)
-            g.set_exchange(hook, rank, world, device_buffers=not a.host_exchange)
+            # (rehearsal: gloo's all-reduce on CUDA tensors of two processes sharing one GPU stalls now and then;
+            # the host-buffer form of the hook is what it exercises)
+            g.set_exchange(hook, rank, world, device_buffers=not (a.host_exchange or rehearsal))
         opt = capi.options("refine")
         opt.function_tolerance = opt.gradient_tolerance = opt.parameter_tolerance = -1.0   # run every iteration asked
 
@@ -275,12 +294,15 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+        trace("handle ready")
         run(a.warmup)
+        trace("warm-up done")
         fence()
         t0 = time.perf_counter()
         last = run(a.steps)
         fence()
         dt = time.perf_counter() - t0
+        trace("timed region done")
         # a second, untimed pass with per-phase hipEvents on the handle's stream (the event records cost a few
         # microseconds of stream bubbles each, so they stay out of the timed region)
         g.enable_timing(True)
@@ -292,7 +314,9 @@ def main():
         # the Schur kernel alone, 20 launches back to back between two hipEvents on the handle's stream: the
         # duration rocprofv3 reports for it (an event pair around a single launch inside a running iteration
         # reads 15-20 us more)
+        trace("phase pass done")
         schur_ms = g.time_schur(20)
+        trace("schur timing done")
 
         # ---- one whole refine() with the reference's own options (calibration.cpp:420-428), start to convergence ----
         fo = capi.options("refine")
@@ -301,6 +325,7 @@ def main():
         tf = time.perf_counter()
         fs = g.solve(fo)
         torch.cuda.synchronize()
+        trace("full refine done")
         full = {"iterations": fs.iterations, "termination": fs.termination, "ms_total": 1e3 * (time.perf_counter() - tf),
                 "initial_cost": fs.initial_cost, "final_cost": fs.final_cost}
 
