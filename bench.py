@@ -241,6 +241,11 @@ def main():
     # over gloo, so that the N > 1 code path -- sharding, device-buffer hook, packed exchange -- runs end to end
     rehearsal = world > 1 and os.environ.get("CVX_BENCH_REHEARSAL") == "1"
 
+    if rehearsal:       # kill -USR1 <pid> prints every thread's Python stack (where a stalled rehearsal sits)
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGUSR1, all_threads=True)
+
     def trace(msg):
         if rehearsal:
             sys.stderr.write("[rank %d] %s\n" % (rank, msg)); sys.stderr.flush()
@@ -272,7 +277,7 @@ def main():
             hook = make_hook(torch, dist, capi)
             # (rehearsal: gloo's all-reduce on CUDA tensors of two processes sharing one GPU stalls now and then;
             # the host-buffer form of the hook is what it exercises)
-            g.set_exchange(hook, rank, world, device_buffers=not (a.host_exchange or rehearsal))
+            g.set_exchange(hook, rank, world, device_buffers=not (a.host_exchange or (rehearsal and os.environ.get("CVX_BENCH_REHEARSAL_DEVICE") != "1")))
         opt = capi.options("refine")
         opt.function_tolerance = opt.gradient_tolerance = opt.parameter_tolerance = -1.0   # run every iteration asked
 
