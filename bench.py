@@ -58,7 +58,12 @@ def make_hook(torch, dist, capi):
         try:
             if on_device:
                 t = torch.as_tensor(_DevBuf(C.cast(buf, C.c_void_p).value, count), device="cuda")
-                dist.all_reduce(t)
+                if dist.get_backend() == "gloo":    # one-GPU rehearsal: gloo's own CUDA path stalls when ranks share a GPU
+                    th = t.cpu()
+                    dist.all_reduce(th)
+                    t.copy_(th)
+                else:
+                    dist.all_reduce(t)
             else:
                 a = np.ctypeslib.as_array(buf, shape=(count,))
                 t = torch.from_numpy(a).cuda()
@@ -275,9 +280,7 @@ def main():
         hook = None
         if world > 1:
             hook = make_hook(torch, dist, capi)
-            # (rehearsal: gloo's all-reduce on CUDA tensors of two processes sharing one GPU stalls now and then;
-            # the host-buffer form of the hook is what it exercises)
-            g.set_exchange(hook, rank, world, device_buffers=not (a.host_exchange or (rehearsal and os.environ.get("CVX_BENCH_REHEARSAL_DEVICE") != "1")))
+            g.set_exchange(hook, rank, world, device_buffers=not a.host_exchange)
         opt = capi.options("refine")
         opt.function_tolerance = opt.gradient_tolerance = opt.parameter_tolerance = -1.0   # run every iteration asked
 
