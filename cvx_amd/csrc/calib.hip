@@ -434,15 +434,21 @@ private:
         }
         ph_end(h, PH_BACKSUBST);
         // one rank, no phase timing: the result lands in host-mapped memory and the host polls its sequence number
-        const bool polled = h->nranks == 1 && !h->timing && h->d_E2_map;
+        // (several ranks with a device-buffer hook: the same, published by a small kernel behind the all-reduce)
+        const bool sharded_dev = h->nranks > 1 && h->xfn && h->xdev;
+        const bool polled = (h->nranks == 1 || sharded_dev) && !h->timing && h->d_E2_map;
         const double seq = (double)(++h->step_seq);
         ph_begin(h, PH_COST);
         hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V,
-                           h->d_out_view, h->V, h->d_E2, polled ? h->d_E2_map : (double *)nullptr, seq);
+                           h->d_out_view, h->V, h->d_E2, (polled && !sharded_dev) ? h->d_E2_map : (double *)nullptr, seq);
         CVX_HIP(hipGetLastError());
         ph_end(h, PH_COST);
-        if (h->nranks > 1 && h->xfn && h->xdev) {
+        if (sharded_dev) {
             if (h->xfn(h->xctx, h->d_E2, 4, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
+            if (polled) {
+                hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, h->stream, h->d_E2, h->d_E2_map, seq);
+                CVX_HIP(hipGetLastError());
+            }
         }
         if (!polled) {
             CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -1367,4 +1367,16 @@ __global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict
     }
 }
 
+// view-sharded runs: the 16 doubles of the step, complete once the candidate's four sums have been all-reduced, go to
+// host-mapped memory the same way k_final_scalars sends them on one rank (data, system-scope fence, sequence number)
+__global__ void __launch_bounds__(64) k_publish_scalars(const double *__restrict__ E2, double *__restrict__ host_copy, double seq) {
+    if (threadIdx.x < 15) host_copy[threadIdx.x] = E2[threadIdx.x];
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) {
+        host_copy[16] = seq;
+        __threadfence_system();
+    }
+}
+
 }  // namespace cvxk
