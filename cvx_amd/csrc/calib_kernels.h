@@ -707,7 +707,7 @@ struct K4Args {
     const int *chk_row0;
     const K4Task *tasks;   // [parts * K4_WAVES], nA = 0 marks an idle wave
     double *slab;          // [n_chunks][nblk][256]
-    int ZC, ZCp, KB, n_chunks, nb, nblk, parts;
+    int ZC, ZCp, KB, n_chunks, nb, nblk, parts;   // ZCp, KB: informational (the kernel uses K4_PITCH, K4_KB)
 };
 
 #define K4_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f64_4x4x4f64(A_, B_, C_, 0, 0, 0)
@@ -806,18 +806,14 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
     if (nstages > 0) { fetch(0); stash(0); }
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
-#ifndef K4_EXP_NOSTAGE
         if (s + 1 < nstages) fetch(s + 1);
-#endif
         const double *src = lds + (size_t)(s & 1) * K4_KB * K4_PITCH;
         if (!GEN || nA > 0) {
 #pragma unroll
             for (int ks = 0; ks < K4_KB; ks += 4) kstep(src + ks * K4_PITCH);
         }
-#ifndef K4_EXP_NOSTAGE
         if (s + 1 < nstages) stash((s + 1) & 1);
         __syncthreads();
-#endif
     }
     if (nA <= 0) return;
     // accumulator r of block (gA, gB), lane l: row 4b + i, column 4((b - r) & 3) + j with i = l >> 4, b = (l >> 2) & 3,
@@ -826,9 +822,6 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
     auto put = [&](int gA, int gB, const double (&v)[4]) {
         const int q = gA * nb - gA * (gA - 1) / 2 + (gB - gA);
         double *out = a.slab + ((size_t)chunk * a.nblk + q) * 256 + (4 * lb + li) * 16 + lj;
-#ifdef K4_EXP_NOSTORE
-        if (v[0] == 1.2345e-300)
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[4 * ((lb - r) & 3)] = v[r];
     };
