@@ -119,6 +119,8 @@ SIGNATURES = {
     "cvx_handeye_cost": (C.c_int, [C.c_void_p, dp, dp]),
     "cvx_handeye_normal_eq": (C.c_int, [C.c_void_p, dp, dp, dp, dp]),
     "cvx_handeye_evaluate": (C.c_int, [C.c_void_p, dp, dp, dp, dp]),
+    "cvx_handeye_normal_eq_static": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_void_p]),
     "cvx_handeye_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "cvx_handeye_solve": (C.c_int, [C.c_void_p, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]),
     "cvx_rotation_to_angle_axis": (None, [dp, dp]),

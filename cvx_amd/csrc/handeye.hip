@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -94,8 +95,8 @@ int device_cost(cvx_handeye *h, const double p[7], double *cost) {
 int device_normal_eq(cvx_handeye *h, const double p[7], double H[36], double g[6], double *cost) {
     int st = upload_p(h, p);
     if (st) return st;
-    hipLaunchKernelGGL(k_he_normal_eq, dim3(h->n_blocks), dim3(256), 0, h->stream, h->d_pairs, h->n, h->d_p7,
-                       h->d_partial);
+    hipLaunchKernelGGL(k_he_normal_eq<PlaneSrc>, dim3(h->n_blocks), dim3(256), 0, h->stream,
+                       PlaneSrc{h->d_pairs, h->n}, h->n, h->d_p7, h->d_partial);
     CVX_HIP(hipGetLastError());
     st = finish(h, HE_ACC);
     if (st) return st;
@@ -269,6 +270,61 @@ extern "C" int cvx_handeye_evaluate(cvx_handeye *h, const double p[7], double *r
     if (Jq) CVX_HIP(hipMemcpyAsync(Jq, dq, 48 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (Jt) CVX_HIP(hipMemcpyAsync(Jt, dt, 36 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// cvx_handeye_normal_eq for callers that cannot allocate.  The block partials of k_he_normal_eq, which the handle
+// keeps in memory it got from hipMalloc, live in a file-scope device array instead: 1024 blocks x 28 doubles per
+// GPU for as long as the process runs.  Its device address differs per GPU and is looked up once per device.
+// -----------------------------------------------------------------------------------------
+namespace {
+constexpr int HE_STATIC_BLOCKS = CVX_HANDEYE_STATIC_MAX_PAIRS / 256;
+constexpr int HE_STATIC_MAX_DEVICES = 64;
+static __device__ __align__(256) double scratch[(size_t)HE_STATIC_BLOCKS * HE_ACC];
+double *g_scratch_ptr[HE_STATIC_MAX_DEVICES];
+std::mutex g_scratch_mutex;
+}  // namespace
+
+extern "C" int cvx_handeye_normal_eq_static(int n_pairs, const double *d_qa, const double *d_ta, const double *d_qb,
+                                            const double *d_tb, const double *d_p7, double *d_out, int device,
+                                            void *stream) {
+    if (n_pairs < 0 || !d_p7 || !d_out || (n_pairs > 0 && (!d_qa || !d_ta || !d_qb || !d_tb))) return CVX_ERR_INVALID_ARG;
+    if (n_pairs > CVX_HANDEYE_STATIC_MAX_PAIRS) {
+        cvx::set_last_error("cvx_handeye_normal_eq_static: n_pairs exceeds CVX_HANDEYE_STATIC_MAX_PAIRS (" +
+                            std::to_string(CVX_HANDEYE_STATIC_MAX_PAIRS) + "), the size its fixed scratch array holds");
+        return CVX_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        cvx::set_last_error("no HIP device visible");
+        return CVX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) return CVX_ERR_NO_DEVICE;
+    if (device >= HE_STATIC_MAX_DEVICES) return CVX_ERR_UNSUPPORTED;
+    CVX_HIP(hipSetDevice(device));
+    double *partial = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            // first call on this device (make it outside any stream capture): this GPU's copy of the array
+            double *ptr = nullptr;
+            CVX_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+            if (!ptr) { cvx::set_last_error("hipGetSymbolAddress returned a null address"); return CVX_ERR_HIP; }
+            g_scratch_ptr[device] = ptr;
+        }
+        partial = g_scratch_ptr[device];
+    }
+    // same grid as the handle's launch, so the sums (and their order) are the same
+    const long long n = n_pairs;
+    const int n_blocks = (int)std::min<long long>(HE_STATIC_BLOCKS, std::max<long long>(1, (n + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_he_normal_eq<AosSrc>, dim3(n_blocks), dim3(256), 0, s, AosSrc{d_qa, d_ta, d_qb, d_tb}, n, d_p7,
+                       partial);
+    CVX_HIP(hipGetLastError());
+    // every block below n_blocks has written its 28 partials; nothing of an earlier call is read
+    hipLaunchKernelGGL(k_he_final_expand, dim3(1), dim3(64), 0, s, partial, n_blocks, d_out);
+    CVX_HIP(hipGetLastError());
     return CVX_OK;
 }
 

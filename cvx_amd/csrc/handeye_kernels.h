@@ -54,6 +54,26 @@ __device__ __forceinline__ Pair load_pair(const double *__restrict__ pairs, long
     return p;
 }
 
+// where a kernel finds its motion pairs: the handle's component planes, or the caller's own device arrays in the
+// layouts cvx_handeye_create takes on the host (qa[n][4], ta[n][3], qb[n][4], tb[n][3])
+struct PlaneSrc {
+    const double *pairs;
+    long long n;
+    __device__ __forceinline__ Pair load(long long i) const { return load_pair(pairs, n, i); }
+};
+struct AosSrc {
+    const double *qa, *ta, *qb, *tb;
+    __device__ __forceinline__ Pair load(long long i) const {
+        Pair p;
+        const double *a = qa + 4 * i, *b = qb + 4 * i;
+        quat_to_R(a[0], a[1], a[2], a[3], p.Ra);
+        p.ta[0] = ta[3 * i]; p.ta[1] = ta[3 * i + 1]; p.ta[2] = ta[3 * i + 2];
+        quat_to_R(b[0], b[1], b[2], b[3], p.Rb);
+        p.tb[0] = tb[3 * i]; p.tb[1] = tb[3 * i + 1]; p.tb[2] = tb[3 * i + 2];
+        return p;
+    }
+};
+
 __device__ __forceinline__ void he_residual(const Pair &p, const double (&Rx)[9], const double (&t)[3],
                                             double (&r)[12]) {
 #pragma unroll
@@ -122,7 +142,8 @@ __global__ void __launch_bounds__(256) k_he_cost(const double *__restrict__ pair
 // packed), J^T r, sum r^2, with J = [Jq * P | Jt], P the plus-Jacobian at q
 //   rows (-x,-y,-z), (w,z,-y), (-z,w,x), (y,-x,w)       (QuaternionParameterization)
 // -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_he_normal_eq(const double *__restrict__ pairs, long long n,
+template <class Src>
+__global__ void __launch_bounds__(256) k_he_normal_eq(const Src src, long long n,
                                                       const double *__restrict__ p7, double *__restrict__ partial) {
     __shared__ double sh[4][HE_ACC];
     const double qw = p7[0], qx = p7[1], qy = p7[2], qz = p7[3];
@@ -141,7 +162,7 @@ __global__ void __launch_bounds__(256) k_he_normal_eq(const double *__restrict__
     for (int k = 0; k < HE_ACC; ++k) acc[k] = 0.0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const Pair p = load_pair(pairs, n, i);
+        const Pair p = src.load(i);
         double r[12], c0[12], c1[12], c2[12];
         he_residual(p, Rx, t, r);
         he_dir(p, dRl[0], c0);
@@ -185,6 +206,27 @@ __global__ void __launch_bounds__(64) k_he_final(const double *__restrict__ part
     double s = 0.0;
     for (int b = 0; b < n_blocks; ++b) s += partial[(size_t)b * width + k];
     out[k] = s;
+}
+
+// the same sum written out as cvx_handeye_normal_eq hands it to its caller: H[36] (mirrored) | g[6] | cost
+__global__ void __launch_bounds__(64) k_he_final_expand(const double *__restrict__ partial, int n_blocks,
+                                                        double *__restrict__ out) {
+    __shared__ double sh[HE_ACC];
+    const int k = threadIdx.x;
+    if (k < HE_ACC) {
+        double s = 0.0;
+        for (int b = 0; b < n_blocks; ++b) s += partial[(size_t)b * HE_ACC + k];
+        sh[k] = s;
+    }
+    __syncthreads();
+    if (k < 36) {
+        const int a = min(k / 6, k % 6), b = max(k / 6, k % 6);
+        out[k] = sh[a * 6 - a * (a - 1) / 2 + (b - a)];
+    } else if (k < 42) {
+        out[k] = sh[21 + (k - 36)];
+    } else if (k == 42) {
+        out[k] = 0.5 * sh[27];
+    }
 }
 
 // -----------------------------------------------------------------------------------------

@@ -212,6 +212,20 @@ int cvx_handeye_cost(cvx_handeye *h, const double p[7], double *cost);
 int cvx_handeye_normal_eq(cvx_handeye *h, const double p[7], double H[36], double g[6], double *cost);
 /* residuals r[n][12] and global Jacobians Jq[n][12][4], Jt[n][12][3] (any may be NULL) */
 int cvx_handeye_evaluate(cvx_handeye *h, const double p[7], double *r, double *Jq, double *Jt);
+/* cvx_handeye_normal_eq without a handle and without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Every pointer is DEVICE memory the caller owns: the pairs in the layouts cvx_handeye_create takes
+ * (d_qa[n][4], d_ta[n][3], d_qb[n][4], d_tb[n][3]), d_p7[7], and d_out[43] = H[36] row-major | g[6] | cost.
+ * The two kernels are enqueued on `stream` (NULL: the default stream) and the call returns without synchronising;
+ * it calls no hipMalloc / hipFree or allocating routine.  The block partials live in a fixed array in the
+ * library's device image (229 376 bytes on every GPU the library runs on, held until the process ends), hence the
+ * limit: n_pairs > CVX_HANDEYE_STATIC_MAX_PAIRS returns CVX_ERR_UNSUPPORTED.  All calls on one GPU share that
+ * array: calls that overlap on one GPU (two streams, two threads) race; calls ordered on one stream do not.
+ * The first call on a device looks up the array's address there: make it outside any stream capture.
+ * Results are bit-identical to cvx_handeye_normal_eq on the same pairs. */
+#define CVX_HANDEYE_STATIC_MAX_PAIRS 262144
+int cvx_handeye_normal_eq_static(int n_pairs, const double *d_qa, const double *d_ta, const double *d_qb,
+                                 const double *d_tb, const double *d_p7, double *d_out, int device, void *stream);
 int cvx_handeye_set_exchange(cvx_handeye *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks,
                              int device_buffers);
 int cvx_handeye_solve(cvx_handeye *h, double p[7], const cvx_lm_options *opt, cvx_lm_summary *summary);
