@@ -9,11 +9,16 @@ A "step" is ONE Levenberg-Marquardt iteration of CameraCalibration::refine
 linearise (residual + Jacobian of every observation, normal-equation blocks, Schur
 contraction), exchange + solve the damped reduced system, back-substitute the poses and
 evaluate the candidate cost.  Workload: BASELINE config 4 -- 8 cameras x 1 250 views of a
-12x9 board = 10 000 pose blocks, 1 080 000 observations PER GPU (weak scaling: view shards,
-replicated shared block, one all-reduce of the reduced system per iteration).
+12x9 board = 10 000 pose blocks, 1 080 000 observations.
+
+--scaling strong (default; what north_star's config 4 says: "~1M corner observations, sharded by view
+across 8 GPUs"): ONE config-4 problem, its views cut into N contiguous ranges balanced by observation
+count (cvx_partition_views), the shared block replicated, one all-reduce of the reduced system and one
+4-double all-reduce per iteration.  --scaling weak: every rank holds its own config-4-sized shard
+(N = 8: 80 000 pose blocks, 8.64 M observations -- config 5's regime).  At N = 1 the two are the same run.
 
 Rank 0 prints one JSON line.  `value` = observations processed by LM iterations per second,
-whole job (N ranks x 1.08 M observations x K iterations / max-over-ranks time); inputs are
+whole job (all ranks' observations x K iterations / max-over-ranks time); inputs are
 resident in HBM before the timed region.  `roofline` is for the kernel that dominates the
 iteration (per-launch hipEvent durations on the handle's stream); `eval` carries the
 materialised residual/Jacobian evaluation (HBM-bound, 328 B/observation); `cpu_baseline`
@@ -48,8 +53,12 @@ class _DevBuf:
 
 
 def make_hook(torch, dist, capi):
-    """cvx_allreduce_fn on torch.distributed (backend nccl = RCCL over xGMI)."""
+    """cvx_allreduce_fn on torch.distributed (backend nccl = RCCL over xGMI).  A device buffer is reduced in place on
+    the stream the library hands over (cvx_amd.h: `stream` is the hipStream_t the data is ordered on): the
+    collective is issued with that stream current, so RCCL's own stream waits for the kernels before it and the
+    library's next kernels wait for the result, whatever torch's current stream is at the time of the call."""
     calls = [0]
+    gloo = dist.get_backend() == "gloo"
 
     def hook(ctx, buf, count, on_device, stream):
         calls[0] += 1
@@ -57,18 +66,23 @@ def make_hook(torch, dist, capi):
             sys.stderr.write("[rank %s] exchange %d: %d doubles\n" % (os.environ.get("RANK"), calls[0], count)); sys.stderr.flush()
         try:
             if on_device:
-                t = torch.as_tensor(_DevBuf(C.cast(buf, C.c_void_p).value, count), device="cuda")
-                if dist.get_backend() == "gloo":    # one-GPU rehearsal: gloo's own CUDA path stalls when ranks share a GPU
-                    th = t.cpu()
-                    dist.all_reduce(th)
-                    t.copy_(th)
-                else:
-                    dist.all_reduce(t)
+                ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()
+                with torch.cuda.stream(ext):
+                    t = torch.as_tensor(_DevBuf(C.cast(buf, C.c_void_p).value, count), device="cuda")
+                    if gloo:    # one-GPU rehearsal: the sum is taken on host copies
+                        th = t.cpu()
+                        dist.all_reduce(th)
+                        t.copy_(th)
+                    else:
+                        dist.all_reduce(t)
             else:
                 a = np.ctypeslib.as_array(buf, shape=(count,))
-                t = torch.from_numpy(a).cuda()
-                dist.all_reduce(t)
-                a[:] = t.cpu().numpy()
+                if gloo:
+                    dist.all_reduce(torch.from_numpy(a))
+                else:
+                    t = torch.from_numpy(a).cuda()
+                    dist.all_reduce(t)
+                    a[:] = t.cpu().numpy()
             return 0
         except Exception as e:      # the C side turns this into CVX_ERR_EXCHANGE
             sys.stderr.write("exchange hook failed: %r\n" % (e,))
@@ -225,6 +239,8 @@ def main():
     ap.add_argument("--cpu-views", type=int, default=1250, help="views per camera of the CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--host-exchange", action="store_true", help="all-reduce host copies instead of device buffers")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: one config-4 problem sharded by view over the ranks; weak: a config-4-sized shard per rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -264,11 +280,24 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- this rank's shard of the global problem: its own 10 000 views, the shared block replicated ----
-    d = cvx_amd.synth_calib(CAMERAS, VIEWS_PER_CAMERA, BOARD_W, BOARD_H, SEED + 1000 * rank)
+    # ---- this rank's shard of the global problem, the shared block replicated ----
+    gloo = world > 1 and dist.get_backend() == "gloo"
+
+    def on_wire(t):     # gloo (rehearsal): CPU tensors only; nccl: device tensors
+        return t if gloo else t.cuda()
+    if a.scaling == "strong" or world == 1:
+        # one config-4 problem (the same on every rank: the generator is deterministic), this rank's range of views
+        full_problem = cvx_amd.synth_calib(CAMERAS, VIEWS_PER_CAMERA, BOARD_W, BOARD_H, SEED)
+        first = cvx_amd.partition_views(full_problem["view_off"], world)
+        d = cvx_amd.shard_calib(full_problem, first, rank) if world > 1 else full_problem
+        n_obs_total = full_problem["N"]
+        del full_problem
+    else:
+        d = cvx_amd.synth_calib(CAMERAS, VIEWS_PER_CAMERA, BOARD_W, BOARD_H, SEED + 1000 * rank)
+        n_obs_total = world * d["N"]
     intr0, pts0 = d["intr_init"].copy(), d["points_init"].copy()
     if world > 1:       # every rank must start from the same shared parameters
-        t = torch.from_numpy(np.concatenate([intr0.ravel(), pts0.ravel()])).cuda()
+        t = on_wire(torch.from_numpy(np.concatenate([intr0.ravel(), pts0.ravel()])))
         dist.broadcast(t, 0)
         flat = t.cpu().numpy()
         intr0 = flat[:intr0.size].reshape(intr0.shape).copy()
@@ -381,7 +410,7 @@ def main():
         toolba = toolba_bench(cvx_amd, torch, local_rank, with_cpu=(world == 1 and not a.no_cpu_baseline))
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = on_wire(torch.tensor([dt], dtype=torch.float64))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -411,35 +440,60 @@ def main():
         achieved = amount / (per_launch[dom] * 1e-3) / scale if per_launch[dom] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes")
             except Exception:
                 traffic = None
+        roof = {"kernel": {"schur": "k_schur_syrk4", "normal_eq": "k_normal_eq", "assemble": "k_reduce_all+k_assemble",
+                           "backsubst": "k_backsubst_cost", "cost": "k_final_scalars",
+                           "solve": "k_damp_prepare+k_chol_step+k_solve_finish"}[dom],
+                "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                "frac": achieved / peak, "traffic": traffic,
+                "avg_launch_ms": per_launch[dom], "algorithmic_per_launch": amount,
+                "timing": "20 back-to-back launches between two hipEvents" if dom == "schur" and schur_ms > 0
+                          else "hipEvent pair around each launch of the phase"}
+        if dom == "schur" and per_launch[dom] > 0:
+            # three ways to count the contraction's flops: `frac` uses SURVEY.md 8(d)'s figure,
+            # the upper triangle of all ns + 1 columns; a view's Z row is zero outside its own camera's columns, so
+            # the non-zero part is smaller; the kernel issues whole 16x16 blocks over the columns of ONE camera
+            t_s = per_launch[dom] * 1e-3
+            cols = 3 * BOARD_W * BOARD_H + 8 + 1      # free points + the view's own camera (k3 fixed) + gradient
+            nonzero = 2.0 * 6 * V * cols * (cols + 1) / 2
+            issued = 512.0 * geo["tile_pairs"] * 6 * V
+            roof.update({
+                "algorithmic_nonzero_per_launch": nonzero, "frac_nonzero": nonzero / t_s / 1e12 / peak,
+                "issued_per_launch": issued, "frac_issued": issued / t_s / 1e12 / peak,
+                "note": "frac counts the upper triangle of all %d columns (SURVEY.md 8d); frac_nonzero leaves out the "
+                        "blocks between different cameras' columns, which are zero by structure; frac_issued is what "
+                        "the MFMA pipe executes: %d blocks of 16x16 per 4 rows" % (ns + 1, geo["tile_pairs"])})
+        # the iteration as a whole against the fp64 peak: SURVEY.md 8(d) flops per step (1 100 per observation on the
+        # vector ALU + the symmetric half of the Schur contraction, 6 ns^2 per view) / wall time per step
+        step_flops = 1100.0 * N + 6.0 * ns * ns * V
+        step_s = dt / a.steps
         out = {
             "metric": "LM iterations/sec + residual/Jacobian evals/sec at 1M obs (observations processed by LM iterations per second)",
-            "value": world * N * a.steps / dt,
+            "value": n_obs_total * a.steps / dt,
             "unit": "observations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps,
             "lm_iterations_per_s": a.steps / dt,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: 8 cameras x 1250 views x 12x9 board per GPU "
-                                   "(10000 pose blocks, 1080000 observations, 388 shared unknowns), "
-                                   "CameraCalibration::refine LM iteration, k3 fixed, board points free",
-                       "observations_per_gpu": N, "views_per_gpu": V, "shared_unknowns": ns,
+            "config": {"workload": ("BASELINE config 4: 8 cameras x 1250 views x 12x9 board (10000 pose blocks, 1080000 "
+                                    "observations, 388 shared unknowns)%s, CameraCalibration::refine LM iteration, "
+                                    "k3 fixed, board points free") % (
+                                        "" if world == 1 else (", ONE problem sharded by view over %d GPUs" % world)
+                                        if a.scaling == "strong" else ", one such shard PER GPU"),
+                       "observations_total": n_obs_total,
+                       "observations_rank0": N, "views_rank0": V, "shared_unknowns": ns,
                        "parallelism": "views sharded over %d GPU(s), one all-reduce of the reduced system per iteration" % world,
                        "iterations_per_solve": ITERS_PER_SOLVE, "accepted_steps_in_last_solve": last.num_successful,
                        "final_cost_after_%d_iterations" % ITERS_PER_SOLVE: last.final_cost},
-            "roofline": {"kernel": {"schur": "k_schur_syrk4", "normal_eq": "k_normal_eq", "assemble": "k_reduce_all+k_assemble",
-                                    "backsubst": "k_backsubst_cost", "cost": "k_final_scalars",
-                                    "solve": "k_damp_prepare+k_chol_step+k_solve_finish"}[dom],
-                         "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": traffic,
-                         "avg_launch_ms": per_launch[dom], "algorithmic_per_launch": amount,
-                         "timing": "20 back-to-back launches between two hipEvents" if dom == "schur" and schur_ms > 0
-                                   else "hipEvent pair around each launch of the phase"},
+            "roofline": roof,
+            "iteration": {"flops_per_step_rank0": step_flops, "achieved": step_flops / step_s / 1e12,
+                          "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_flops / step_s / 1e12 / F64_PEAK_TFLOPS,
+                          "note": "SURVEY.md 8(d) flops of one LM iteration on rank 0's shard / ms_per_step"},
             "phases_ms_per_iteration": per_iter,
             "device_ms_per_iteration": sum(per_iter.values()),
             "eval": {"kernel": "k_eval", "ms": eval_ms, "observations_per_s": N / (eval_ms * 1e-3),

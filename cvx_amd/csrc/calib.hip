@@ -82,6 +82,7 @@ struct cvx_calib {
     double *d_E2_map = nullptr;      // device view of h_E2 (host-mapped, fine-grained)
     long long step_seq = 0;
     double *d_eval = nullptr;
+    double *d_best = nullptr;        // intr | points | poses of the lowest-cost point (non-monotonic runs)
     // device: damped reduced solve (solve_kernels.h)
     int npad = 32, nT = 1;
     double *d_A = nullptr, *d_L = nullptr, *d_s2sh = nullptr, *d_Ds = nullptr, *d_delta_s = nullptr;
@@ -109,7 +110,7 @@ cvx_calib::~cvx_calib() {
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
-                    d_E2, d_eval, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X};
+                    d_E2, d_eval, d_best, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -139,6 +140,8 @@ inline void ph_collect(cvx_calib *h) {
             h->ph_used[i] = false;
         }
 }
+
+static_assert(CVX_MAX_MARKERS_PER_VIEW <= 512, "k_normal_eq runs one observation per lane in workgroups of at most 512");
 
 template <int MODE>
 int launch_normal_eq(cvx_calib *h, const K2Args &a) {
@@ -373,6 +376,29 @@ public:
 
     int accept() override {
         h->cur = 1 - h->cur;
+        return CVX_OK;
+    }
+
+    // the lowest-cost point of a non-monotonic run: a third set of parameter buffers, made on first need
+    int save_best() override {
+        const size_t ni = 9 * (size_t)h->C, np = 3 * (size_t)h->P, nv = 6 * (size_t)h->V;
+        if (!h->d_best) {
+            int st = dev_alloc(&h->d_best, ni + np + nv);
+            if (st) return st;
+        }
+        CVX_HIP(hipMemcpyAsync(h->d_best, h->d_intr[h->cur], ni * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        CVX_HIP(hipMemcpyAsync(h->d_best + ni, h->d_points[h->cur], np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (nv) CVX_HIP(hipMemcpyAsync(h->d_best + ni + np, h->d_poses[h->cur], nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        return CVX_OK;
+    }
+    int restore_best() override {
+        if (!h->d_best) return CVX_ERR_INVALID_ARG;
+        const size_t ni = 9 * (size_t)h->C, np = 3 * (size_t)h->P, nv = 6 * (size_t)h->V;
+        CVX_HIP(hipMemcpyAsync(h->d_intr[h->cur], h->d_best, ni * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        CVX_HIP(hipMemcpyAsync(h->d_points[h->cur], h->d_best + ni, np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (nv) CVX_HIP(hipMemcpyAsync(h->d_poses[h->cur], h->d_best + ni + np, nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        h->rt_valid[h->cur] = false;
+        CVX_HIP(hipStreamSynchronize(h->stream));
         return CVX_OK;
     }
 
@@ -788,16 +814,16 @@ extern "C" int cvx_calib_evaluate(cvx_calib *h, double *cost, double *r, double 
     std::vector<double> buf(38 * N);
     if (N) CVX_HIP(hipMemcpyAsync(buf.data(), h->d_eval, sizeof(double) * 38 * N, hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
-    double s = 0;
+    long double s = 0;      // 10^7 terms in one running sum: the extended accumulator keeps it at 1e-16
     for (size_t o = 0; o < N; ++o) {
         const double r0 = buf[o], r1 = buf[N + o];
-        s += r0 * r0 + r1 * r1;
+        s += (long double)(r0 * r0 + r1 * r1);
         if (r) { r[2 * o] = r0; r[2 * o + 1] = r1; }
         if (Jc) for (int i = 0; i < 18; ++i) Jc[18 * o + i] = buf[(2 + i) * N + o];
         if (Jp) for (int i = 0; i < 12; ++i) Jp[12 * o + i] = buf[(20 + i) * N + o];
         if (Jx) for (int i = 0; i < 6; ++i) Jx[6 * o + i] = buf[(32 + i) * N + o];
     }
-    if (cost) *cost = 0.5 * s;
+    if (cost) *cost = (double)(0.5L * s);
     return CVX_OK;
 }
 

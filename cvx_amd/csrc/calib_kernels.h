@@ -852,6 +852,10 @@ __global__ void __launch_bounds__(64 * K4_WAVES, 2) k_schur_syrk4(K4Args a) {
     t.diag = __builtin_amdgcn_readfirstlane(t.diag); t.edge = __builtin_amdgcn_readfirstlane(t.edge);
     t.corner = __builtin_amdgcn_readfirstlane(t.corner);
     const bool whole = t.nA == 4 && t.nB == 4;
+    // The waves of a workgroup run different k4_body instantiations and still meet at the same barriers: s_barrier
+    // counts arrivals, not program counters.  The invariant every instantiation keeps is the NUMBER of barriers a
+    // wave executes, nstages + 1 (one after the first stage is stashed, one per stage), and nstages depends on the
+    // chunk alone; idle waves (nA = 0) take part in the staging and in every barrier before they return.
     if (!t.diag) {
         if (whole) k4_body<0>(a, t, chunk, lds); else k4_body<3>(a, t, chunk, lds);
     } else if (whole) {

@@ -196,6 +196,13 @@ public:
         lin_valid = false;
         return CVX_OK;
     }
+    double xbest[7];
+    int save_best() override { std::memcpy(xbest, x, sizeof x); return CVX_OK; }
+    int restore_best() override {
+        std::memcpy(x, xbest, sizeof x);
+        lin_valid = false;
+        return CVX_OK;
+    }
 };
 
 }  // namespace

@@ -13,6 +13,7 @@
 #include <cfloat>
 
 #include "common.h"
+#include "nielsen.h"
 
 namespace cvxhom {
 
@@ -201,9 +202,9 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
     double p[8], pDp[8], Dp[8], jte[8], diag[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { p[i] = Hp[i]; diag[i] = 0.0; jte[i] = 0.0; Dp[i] = 0.0; pDp[i] = 0.0; }
-    const double eps2_sq = a.eps2 * a.eps2;
-    double mu = 0.0, jacTe_inf = 0.0, p_L2 = 0.0, Dp_L2 = DBL_MAX, p_eL2, pDp_eL2, ajj = 0.0;
-    int nu = 2, stop = 0, nfev = 1, njev = 0, nlss = 0, k;
+    cvx::NielsenDamping damp = {0.0, 2};
+    double grad_inf = 0.0, param_sq = 0.0, step_sq = DBL_MAX, err_sq, cand_sq, ajj = 0.0;
+    int stop = cvx::NS_RUNNING, n_eval = 1, n_jac = 0, n_solve = 0, outer;
 #ifdef HOM_PROF
     long long prof_acc[4] = {0, 0, 0, 0};
     const long long prof_t0 = clock64();
@@ -212,15 +213,17 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
     __syncthreads();
     hom_eval<false>(P, N, p, Q, E, lane);
     __syncthreads();
-    p_eL2 = hom_norm2(E, n, lane);
-    const double init_p_eL2 = p_eL2;
-    if (!isfinite(p_eL2)) stop = 7;
+    err_sq = hom_norm2(E, n, lane);
+    const double first_err_sq = err_sq;
+    if (!isfinite(err_sq)) stop = cvx::NS_NOT_FINITE;
 
-    for (k = 0; k < a.itmax && !stop; ++k) {
-        if (p_eL2 <= a.eps3) { stop = 6; break; }
+    // outer loop: one linearisation per pass; inner loop: raise mu until a step reduces the error.  All decisions are
+    // wave-uniform (the same values on every lane); damping schedule and step tests: nielsen.h
+    for (outer = 0; outer < a.itmax && stop == cvx::NS_RUNNING; ++outer) {
+        if (err_sq <= a.eps3) { stop = cvx::NS_SMALL_RESIDUAL; break; }
         __syncthreads();
         HOM_T(0, hom_eval<true>(P, N, p, Q, E, lane); __syncthreads())
-        ++njev;
+        ++n_jac;
         __syncthreads();
 #ifdef HOM_PROF
         const long long prof_ts = clock64();
@@ -285,62 +288,54 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
 #endif
         __syncthreads();
         ajj = entry >= 0 ? S[entry] : 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { jte[i] = S[21 + i]; diag[i] = S[hom_entry(i, i)]; }
-        p_L2 = 0.0; jacTe_inf = 0.0;
+        param_sq = 0.0; grad_inf = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double t = fabs(jte[i]);
-            if (jacTe_inf < t) jacTe_inf = t;
-            p_L2 += p[i] * p[i];
+            jte[i] = S[21 + i]; diag[i] = S[hom_entry(i, i)];
+            grad_inf = (grad_inf < fabs(jte[i])) ? fabs(jte[i]) : grad_inf;
+            param_sq += p[i] * p[i];
         }
-        if (jacTe_inf <= a.eps1) { Dp_L2 = 0.0; stop = 1; break; }
-        if (k == 0) {
-            double t = -DBL_MAX;
+        if (grad_inf <= a.eps1) { step_sq = 0.0; stop = cvx::NS_SMALL_GRADIENT; break; }
+        if (outer == 0) {
+            double widest = -DBL_MAX;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) if (diag[i] > t) t = diag[i];
-            mu = a.tau * t;
+            for (int i = 0; i < 8; ++i) widest = (diag[i] > widest) ? diag[i] : widest;
+            damp.mu = a.tau * widest;
         }
         const double brow = S[21 + r];
         for (;;) {
-            const double aug = (r == c) ? ajj + mu : ajj;
-            bool ok;
-            HOM_T(3, ok = hom_lu_solve(aug, brow, lane, Dp))
-            ++nlss;
-            if (ok) {
-                Dp_L2 = 0.0;
+            const double aug = (r == c) ? ajj + damp.mu : ajj;
+            bool solved;
+            HOM_T(3, solved = hom_lu_solve(aug, brow, lane, Dp))
+            ++n_solve;
+            if (solved) {
+                step_sq = 0.0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { pDp[i] = p[i] + Dp[i]; Dp_L2 += Dp[i] * Dp[i]; }
-                if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
-                if (Dp_L2 >= (p_L2 + a.eps2) / (1e-12 * 1e-12)) { stop = 4; break; }
+                for (int i = 0; i < 8; ++i) { pDp[i] = p[i] + Dp[i]; step_sq += Dp[i] * Dp[i]; }
+                stop = cvx::nielsen_step_test(step_sq, param_sq, a.eps2);
+                if (stop != cvx::NS_RUNNING) break;
                 __syncthreads();
                 HOM_T(0, hom_eval<false>(P, N, pDp, Q, E, lane); __syncthreads())
-                ++nfev;
+                ++n_eval;
                 __syncthreads();
-                HOM_T(2, pDp_eL2 = hom_norm2(E, n, lane))
-                if (!isfinite(pDp_eL2)) { stop = 7; break; }
-                double dL = 0.0;
+                HOM_T(2, cand_sq = hom_norm2(E, n, lane))
+                if (!isfinite(cand_sq)) { stop = cvx::NS_NOT_FINITE; break; }
+                double predicted = 0.0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dL += Dp[i] * (mu * Dp[i] + jte[i]);
-                const double dF = p_eL2 - pDp_eL2;
-                if (dL > 0.0 && dF > 0.0) {
-                    double t = 2.0 * dF / dL - 1.0;
-                    t = 1.0 - t * t * t;
-                    mu = mu * ((t >= 0.3333333334) ? t : 0.3333333334);
-                    nu = 2;
+                for (int i = 0; i < 8; ++i) predicted += Dp[i] * (damp.mu * Dp[i] + jte[i]);
+                const double actual = err_sq - cand_sq;
+                if (predicted > 0.0 && actual > 0.0) {
+                    damp.relax(actual, predicted);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) p[i] = pDp[i];
-                    p_eL2 = pDp_eL2;
+                    err_sq = cand_sq;
                     break;
                 }
             }
-            mu *= nu;
-            const int nu2 = (int)((unsigned)nu << 1);
-            if (nu2 <= nu) { stop = 5; break; }
-            nu = nu2;
+            if (!damp.tighten()) { stop = cvx::NS_NO_REDUCTION; break; }
         }
     }
-    if (k >= a.itmax && !stop) stop = 3;
+    if (outer >= a.itmax && stop == cvx::NS_RUNNING) stop = cvx::NS_ITERATION_LIMIT;
 
 #ifdef HOM_PROF
     if (lane == 0 && a.prof) {
@@ -352,14 +347,15 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) Hp[i] = p[i];
         Hp[8] = 1.0;                                   // homography.cpp:233
-        if (a.ret) a.ret[prob] = (stop != 4 && stop != 7) ? k : -1;
+        if (a.ret) a.ret[prob] = (stop != cvx::NS_NEAR_SINGULAR && stop != cvx::NS_NOT_FINITE) ? outer : -1;
         if (a.info) {
             double mx = DBL_MIN;
 #pragma unroll
             for (int i = 0; i < 8; ++i) if (diag[i] > mx) mx = diag[i];
             double *o = a.info + (size_t)prob * 10;
-            o[0] = init_p_eL2; o[1] = p_eL2; o[2] = jacTe_inf; o[3] = Dp_L2; o[4] = mu / mx;
-            o[5] = (double)k; o[6] = (double)stop; o[7] = (double)nfev; o[8] = (double)njev; o[9] = (double)nlss;
+            // levmar's info[0..9] (levmar.h:60-75)
+            o[0] = first_err_sq; o[1] = err_sq; o[2] = grad_inf; o[3] = step_sq; o[4] = damp.mu / mx;
+            o[5] = (double)outer; o[6] = (double)stop; o[7] = (double)n_eval; o[8] = (double)n_jac; o[9] = (double)n_solve;
         }
     }
 }

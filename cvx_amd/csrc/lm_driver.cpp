@@ -1,4 +1,5 @@
 #include "lm_driver.h"
+#include "nielsen.h"
 
 #include <chrono>
 #include <cfloat>
@@ -34,6 +35,9 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
     const int max_nonmono = o.nonmonotonic ? o.max_consecutive_nonmonotonic_steps : 0;
     int term = 0, invalid_run = 0, it = 0;
     bool need_gcheck = false;   // the gradient at the current point has not been tested yet
+    // lowest-cost point visited: the current one until an uphill step is accepted
+    double best_cost = cost;
+    bool best_is_current = true;
     if (gmax <= o.gradient_tolerance) term = 1;
 
     while (!term) {
@@ -80,6 +84,13 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
         const double rho = (max_nonmono > 0 && hist > rel) ? hist : rel;
         if (rho > o.min_relative_decrease) {
             trace_push(sum, cand, 1, radius, gmax);
+            if (cand < best_cost) {
+                best_cost = cand; best_is_current = true;
+            } else if (best_is_current) {
+                int sb = ev.save_best();
+                if (sb) return sb;
+                best_is_current = false;
+            }
             int st = ev.accept();
             if (st) return st;
             cost = cand;
@@ -102,6 +113,11 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
             if (radius < o.min_radius) { term = 5; break; }
         }
     }
+    if (!best_is_current) {
+        int rb = ev.restore_best();
+        if (rb) return rb;
+        cost = best_cost;
+    }
     sum.iterations = it;
     sum.termination = term;
     sum.final_cost = cost;
@@ -109,65 +125,56 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
 }
 
 // ---------------------------------------------------------------------------------------
-// strategy 1: levmar (Nielsen damping), lm_core.c:163-409
+// strategy 1: the Nielsen-damped loop of the reference's levmar (dlevmar_der, lm_core.c:163-409): same tests in the
+// same order on the same quantities, so that a run reproduces the reference's info[] -- damping schedule and step
+// tests in nielsen.h
 // ---------------------------------------------------------------------------------------
-// constants of the reference's levmar build, levmar/lm.c:35-36
-static const double LM_EPSILON = 1E-12, LM_ONE_THIRD = 0.3333333334;
-
 static int lm_nielsen(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summary &sum) {
     InitInfo ini = ev.init(false);
     if (ini.status) return ini.status;
-    double p_eL2 = 2.0 * ini.cost;
     sum.initial_cost = ini.cost;
-    const double eps2_sq = o.eps2 * o.eps2;
-    double mu = 0;
-    int nu = 2, stop = 0, k;
-    if (!std::isfinite(p_eL2)) stop = 7;
-    for (k = 0; k < o.max_iterations && !stop; ++k) {
-        if (p_eL2 <= o.eps3) { stop = 6; break; }
-        if (k == 0) mu = o.tau * ini.diag_max;
-        bool first = true;
-        for (;;) {
-            cvx_damping d = {0.0, mu, 0.0, 0.0};
-            StepInfo s = ev.try_step(d, first ? o.eps1 : -1.0, false);
+    double err_sq = 2.0 * ini.cost;                 // |e|^2 at the current point
+    NielsenDamping damp = {0.0, 2};
+    int stop = std::isfinite(err_sq) ? NS_RUNNING : NS_NOT_FINITE;
+    int outer = 0;
+    for (; outer < o.max_iterations && stop == NS_RUNNING; ++outer) {
+        if (err_sq <= o.eps3) { stop = NS_SMALL_RESIDUAL; break; }
+        if (outer == 0) damp.mu = o.tau * ini.diag_max;
+        // inner loop: raise mu until a step reduces the error (or a test fires)
+        for (bool first = true;; first = false) {
+            const cvx_damping d = {0.0, damp.mu, 0.0, 0.0};
+            const StepInfo s = ev.try_step(d, first ? o.eps1 : -1.0, false);
             if (s.status) return s.status;
-            if (first && s.grad_converged) { stop = 1; break; }
-            first = false;
+            if (first && s.grad_converged) { stop = NS_SMALL_GRADIENT; break; }
             sum.num_linear_solves++;
-            if (s.ok) {
-                const double Dp_L2 = s.step_norm2, p_L2 = s.free_norm2;
-                if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
-                if (Dp_L2 >= (p_L2 + o.eps2) / (LM_EPSILON * LM_EPSILON)) { stop = 4; break; }
-                const double pDp_eL2 = 2.0 * s.cand_cost;
-                if (!std::isfinite(pDp_eL2)) { stop = 7; break; }
-                const double dL = 2.0 * s.model_change;   // sum delta (mu delta - g)
-                const double dF = p_eL2 - pDp_eL2;
-                if (dL > 0.0 && dF > 0.0) {
-                    trace_push(sum, s.cand_cost, 1, mu, s.grad_max);
-                    double t = 2.0 * dF / dL - 1.0;
-                    t = 1.0 - t * t * t;
-                    mu = mu * ((t >= LM_ONE_THIRD) ? t : LM_ONE_THIRD);
-                    nu = 2;
-                    int st = ev.accept();
+            if (!s.ok) {
+                trace_push(sum, NAN, 0, damp.mu, s.grad_max);
+            } else {
+                stop = nielsen_step_test(s.step_norm2, s.free_norm2, o.eps2);
+                if (stop != NS_RUNNING) break;
+                const double cand_sq = 2.0 * s.cand_cost;
+                if (!std::isfinite(cand_sq)) { stop = NS_NOT_FINITE; break; }
+                const double predicted = 2.0 * s.model_change;      // sum delta (mu delta - g)
+                const double actual = err_sq - cand_sq;
+                if (predicted > 0.0 && actual > 0.0) {
+                    trace_push(sum, s.cand_cost, 1, damp.mu, s.grad_max);
+                    damp.relax(actual, predicted);
+                    const int st = ev.accept();
                     if (st) return st;
-                    p_eL2 = pDp_eL2;
+                    err_sq = cand_sq;
                     sum.num_successful++;
                     break;
                 }
-                trace_push(sum, s.cand_cost, 0, mu, s.grad_max);
-            } else {
-                trace_push(sum, NAN, 0, mu, s.grad_max);
+                trace_push(sum, s.cand_cost, 0, damp.mu, s.grad_max);
             }
-            mu *= nu;
-            int nu2 = nu << 1;
-            if (nu2 <= nu) { stop = 5; break; }
-            nu = nu2;
+            if (!damp.tighten()) { stop = NS_NO_REDUCTION; break; }
         }
+        if (stop == NS_SMALL_GRADIENT) break;       // the reference tests the gradient before its inner loop: no count
     }
-    if (k >= o.max_iterations && !stop) stop = 3;
-    sum.iterations = k;
+    if (outer >= o.max_iterations && stop == NS_RUNNING) stop = NS_ITERATION_LIMIT;
+    sum.iterations = outer;
     sum.termination = stop;
-    sum.final_cost = 0.5 * p_eL2;
+    sum.final_cost = 0.5 * err_sq;
     return CVX_OK;
 }
 

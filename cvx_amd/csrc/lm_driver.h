@@ -46,6 +46,12 @@ public:
     virtual StepInfo try_step(const cvx_damping &d, double gtol, bool gradient_only) = 0;
     // current point <- last candidate
     virtual int accept() = 0;
+    // Non-monotonic runs may accept uphill steps and must hand back the lowest-cost point they visited (what
+    // ceres::Solve documents for use_nonmonotonic_steps, set at calibration.cpp:421): save_best() copies the
+    // current point aside -- called before an uphill accept leaves the best point behind -- and restore_best()
+    // makes that copy the current point again.
+    virtual int save_best() = 0;
+    virtual int restore_best() = 0;
 };
 
 int lm_minimize(Evaluator &ev, const cvx_lm_options &opt, cvx_lm_summary &sum);

@@ -269,6 +269,13 @@ public:
         lin_valid = false;
         return CVX_OK;
     }
+    std::vector<double> xbest;
+    int save_best() override { xbest = x; return CVX_OK; }
+    int restore_best() override {
+        x = xbest;
+        lin_valid = false;
+        return CVX_OK;
+    }
 
 };
 

@@ -122,9 +122,11 @@ typedef struct {
     void *stream;             /* hipStream_t to run on, or NULL: the handle creates its own */
 } cvx_calib_desc;
 
-/* limits of this build (CVX_ERR_UNSUPPORTED beyond them) */
-#define CVX_MAX_MARKERS_PER_VIEW 1024
+/* limits of this build (cvx_calib_create returns CVX_ERR_UNSUPPORTED beyond them).  A view lists a board point
+ * at most once (CVX_ERR_DUPLICATE_MARKER), so its marker count is bounded by the point count; the normal-equation
+ * kernel runs one observation per lane in workgroups of up to 512 lanes. */
 #define CVX_MAX_POINTS 448
+#define CVX_MAX_MARKERS_PER_VIEW CVX_MAX_POINTS
 #define CVX_MAX_CAMERAS 64
 
 int cvx_calib_create(const cvx_calib_desc *desc, cvx_calib **out);

@@ -527,17 +527,22 @@ static double gradient_max_norm(const lm_model *m, const double *x, const double
 
 /* Ceres-style Levenberg-Marquardt trust region (TrustRegionMinimizer +
  * LevenbergMarquardtStrategy + TrustRegionStepEvaluator), restated from the
- * published algorithm; inner iterations are not restated. */
+ * published algorithm; inner iterations are not restated and every linear solve
+ * is exact.  With non-monotonic steps the lowest-cost point visited is what the
+ * run returns (documented behaviour of use_nonmonotonic_steps). */
 static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_lm_summary *sum) {
     const int nf = m->nfree, ng = m->nglobal;
     double *diag = malloc(sizeof(double) * nf), *grad = malloc(sizeof(double) * nf);
     double *s2 = malloc(sizeof(double) * nf), *D = malloc(sizeof(double) * nf);
     double *delta = malloc(sizeof(double) * nf), *tmpd = malloc(sizeof(double) * nf);
     double *xc = malloc(sizeof(double) * ng), *tmpx = malloc(sizeof(double) * ng);
+    double *xbest = malloc(sizeof(double) * ng);
     memset(sum, 0, sizeof *sum);
 
     double cost = m->linearize(m->ctx, x, diag, grad);
     sum->initial_cost = cost;
+    double best_cost = cost;
+    memcpy(xbest, x, sizeof(double) * ng);
     for (int i = 0; i < nf; ++i) {
         if (o->jacobi_scaling) { double s = 1.0 / (1.0 + sqrt(diag[i])); s2[i] = s * s; }
         else s2[i] = 1.0;
@@ -596,6 +601,7 @@ static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_l
         if (rho > o->min_relative_decrease) {
             trace_push(sum, cand, 1, radius, gmax);
             memcpy(x, xc, sizeof(double) * ng);
+            if (cand < best_cost) { best_cost = cand; memcpy(xbest, x, sizeof(double) * ng); }
             /* LevenbergMarquardtStrategy::StepAccepted */
             double t = 2.0 * rho - 1.0;
             double f = 1.0 - t * t * t; if (f < 1.0 / 3.0) f = 1.0 / 3.0;
@@ -616,8 +622,9 @@ static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_l
             if (radius < o->min_radius) { term = 5; break; }
         }
     }
+    if (best_cost < cost) { memcpy(x, xbest, sizeof(double) * ng); cost = best_cost; }
     sum->iterations = it; sum->termination = term; sum->final_cost = cost;
-    free(diag); free(grad); free(s2); free(D); free(delta); free(tmpd); free(xc); free(tmpx);
+    free(diag); free(grad); free(s2); free(D); free(delta); free(tmpd); free(xc); free(tmpx); free(xbest);
     return term;
 }
 

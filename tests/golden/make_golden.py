@@ -8,7 +8,7 @@ Part A  levmar_kat.json      the reference's vendored levmar 2.5 (compiled from 
                              oracle/_ref/liblevmar_ref.so by oracle/Makefile, never copied) run on its own
                              demo problems (lmdemo.c:49-230, set-ups lmdemo.c:860-961; Osborne data also at
                              modules/util/test/test_lm.cpp:16-21, stated minimum test_lm.cpp:62).
-Part B  levmar_calib_trace.json, levmar_handeye_trace.json
+Part B  levmar_calib_trace.json, levmar_calib_fixed_points_trace.json, levmar_handeye_trace.json
                              the same levmar driven by the oracle's residual/Jacobian callbacks on BASELINE
                              config 1 (20 views of a 9x6 board) and config 2 (200 poses, moving camera).
 Part C  functor_mp.json      50-digit mpmath evaluation of the two cost functors and their Jacobians
@@ -169,6 +169,43 @@ HANDEYE_SPEC = {"n_poses": 200, "seed": 20260002, "moving": True}
 LMSOLVER_OPTS = [1e-3, 2.220446049250313e-16, 2.220446049250313e-16, 2.220446049250313e-16]   # lm.hpp:43-50,61
 
 
+def part_b_fixed_points():
+    """BASELINE config 1 with the board points held fixed: the gauge freedom of refine() (rigid motion + scale of the
+    board, calibration.cpp:405 commented out) is gone, the minimiser is unique, and the dense-LU levmar run and a
+    Schur-complement run walk the same path to rounding level -- the trace a GPU run can be held to tightly."""
+    d = cvx_amd.synth_calib(**CALIB_SPEC)
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"], fix_points=True)
+    C_, V = d["C"], d["V"]
+    m, n = o.nfree, 2 * d["N"]
+    assert m == 8 * C_ + 6 * V
+    cols = [0, 1, 2, 3, 4, 5, 7, 8]
+
+    def unpack(p):
+        intr = d["intr_init"].copy()
+        for c in range(C_):
+            intr[c, cols] = p[c * 8:(c + 1) * 8]
+        return intr, np.array(p[C_ * 8:C_ * 8 + 6 * V]).reshape(V, 6), d["points_init"]
+
+    evals = []
+
+    def func(p, hx, m_, n_, _):
+        r = o.eval(*unpack(np.ctypeslib.as_array(p, shape=(m_,))))[0].reshape(-1)
+        np.ctypeslib.as_array(hx, shape=(n_,))[:] = r
+        evals.append(float(np.dot(r, r)))
+
+    def jac(p, out, m_, n_, _):
+        J = o.dense_jacobian(*unpack(np.ctypeslib.as_array(p, shape=(m_,))))
+        assert J.shape == (n_, m_)
+        np.ctypeslib.as_array(out, shape=(n_ * m_,))[:] = J.reshape(-1)
+
+    p0 = np.concatenate([d["intr_init"][:, cols].reshape(-1), d["poses_init"].reshape(-1)])
+    ret, p, info = run_ref_levmar(orc.LM_FUNC(func), orc.LM_FUNC(jac), p0, np.zeros(n), 100, LMSOLVER_OPTS)
+    print("B calib, points fixed: ret=%d reason=%d |e|^2 %.10g -> %.10g, %d evals" % (ret, int(info[6]), info[0], info[1], len(evals)))
+    json.dump({"spec": CALIB_SPEC, "fix_points": True, "opts": LMSOLVER_OPTS, "itmax": 100, "m": m, "n": n, "ret": ret,
+               "p": p.tolist(), "info": info.tolist(), "evals": evals},
+              open(os.path.join(HERE, "levmar_calib_fixed_points_trace.json"), "w"), indent=1)
+
+
 def part_b():
     d = cvx_amd.synth_calib(**CALIB_SPEC)
     o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
@@ -209,6 +246,8 @@ def part_b():
     json.dump({"spec": CALIB_SPEC, "opts": LMSOLVER_OPTS, "itmax": 100, "m": m, "n": n, "ret": ret,
                "p": p.tolist(), "info": info.tolist(), "evals": evals},
               open(os.path.join(HERE, "levmar_calib_trace.json"), "w"), indent=1)
+
+    part_b_fixed_points()
 
     # hand-eye, 7 global parameters (no parameterisation: this pins the functor and its global Jacobian)
     G, T, xg, x0 = cvx_amd.synth_handeye(HANDEYE_SPEC["n_poses"], HANDEYE_SPEC["seed"], moving=HANDEYE_SPEC["moving"])

@@ -38,6 +38,21 @@ def test_bench_hook_reduces_device_and_host_buffers_in_place():
             v += 1.0
             torch.cuda.synchronize()
             assert torch.equal(t, ref + 1.0)
+            # the hook orders the collective on the stream it is GIVEN, not on torch's current one: data written on a
+            # side stream behind a long-running kernel is what gets reduced, and work queued on that stream
+            # afterwards sees the result, while the current stream is a different one
+            side = torch.cuda.Stream()
+            w = torch.ones(4096, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(20_000_000)
+                w.fill_(3.0)
+            assert torch.cuda.current_stream().cuda_stream != side.cuda_stream
+            rc = hook(None, C.cast(w.data_ptr(), capi.dp), w.numel(), 1, C.c_void_p(side.cuda_stream))
+            with torch.cuda.stream(side):
+                w2 = w * 2.0
+            torch.cuda.synchronize()
+            assert rc == 0 and bool((w == 3.0).all()) and bool((w2 == 6.0).all())
             h = np.arange(16, dtype=np.float64)
             rc = hook(None, capi.pd(h), h.size, 0, None)
             assert rc == 0 and np.array_equal(h, np.arange(16, dtype=np.float64))

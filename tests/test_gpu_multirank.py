@@ -44,6 +44,20 @@ def _worker(rank, world, port, out):
     intr, poses, pts = g.get_params()
     res = {"it": s.iterations, "term": s.termination, "cost": s.final_cost, "trace": s.trace()["cost"].tolist(),
            "intr": intr.tolist(), "pts": pts.tolist(), "poses": poses.tolist(), "v0": int(first[rank])}
+    # the same solve over the device-buffer protocol, the path a real RCCL run takes on the C side (packed lower
+    # triangle exchanged in place on the device, k_damp_prepare reading it, the 4-double all-reduce of the candidate
+    # scalars, k_publish_scalars + the host poll), with bench.py's own hook: under gloo it wraps the device pointer
+    # on the stream the library hands over and takes the sum on host copies
+    import bench
+    g2 = cvx_amd.Calib(sh["cam_of_view"], sh["view_off"], sh["point_id"], sh["obs_x"], sh["obs_y"], d["C"], d["P"])
+    cb2 = bench.make_hook(torch, dist, capi)
+    g2.set_exchange(cb2, rank, world, device_buffers=True)
+    g2.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
+    s2 = g2.solve(capi.options("refine"))
+    intr2, poses2, pts2 = g2.get_params()
+    res["dev"] = {"it": s2.iterations, "term": s2.termination, "cost": s2.final_cost, "trace": s2.trace()["cost"].tolist(),
+                  "intr": intr2.tolist(), "pts": pts2.tolist(), "poses": poses2.tolist()}
+    g2.close()
     # hand-eye shards by pair
     G, T, xg, x0 = cvx_amd.synth_handeye(40, 9)
     A, B = cvx_amd.handeye_pairs(G, T)
@@ -81,6 +95,18 @@ def test_two_rank_solve_equals_single_rank():
     assert np.max(np.abs(np.array(r0["intr"]) - intr) / np.maximum(np.abs(intr), 1e-3)) < 1e-9
     got_poses = np.concatenate([np.array(r0["poses"]), np.array(r1["poses"])])
     assert np.max(np.abs(got_poses - poses)) < 1e-8 * np.max(np.abs(poses))
+    # device-buffer protocol: the same iterations, termination, trace and parameters; identical shared blocks on both ranks
+    d0, d1 = r0["dev"], r1["dev"]
+    assert d0["intr"] == d1["intr"] and d0["pts"] == d1["pts"] and d0["trace"] == d1["trace"]
+    assert (d0["it"], d0["term"]) == (s.iterations, s.termination)
+    trd = np.array(d0["trace"])
+    assert np.all(np.abs(trd - s.trace()["cost"]) <= 1e-10 * trd)
+    assert np.all(np.abs(trd - tr) <= 1e-12 * tr)          # and it agrees with the host-buffer protocol
+    assert abs(d0["cost"] - s.final_cost) <= 1e-11 * s.final_cost
+    assert np.max(np.abs(np.array(d0["intr"]) - intr) / np.maximum(np.abs(intr), 1e-3)) < 1e-9
+    assert np.max(np.abs(np.array(d0["pts"]) - pts)) < 1e-9 * np.max(np.abs(pts))
+    got_poses = np.concatenate([np.array(d0["poses"]), np.array(d1["poses"])])
+    assert np.max(np.abs(got_poses - poses)) < 1e-8 * np.max(np.abs(poses))
     # hand-eye
     G, T, xg, x0 = cvx_amd.synth_handeye(40, 9)
     A, B = cvx_amd.handeye_pairs(G, T)
@@ -89,6 +115,65 @@ def test_two_rank_solve_equals_single_rank():
     assert r0["he_p"] == r1["he_p"]
     assert np.max(np.abs(np.array(r0["he_p"]) - p)) < 1e-12 and abs(r0["he_cost"] - hs.final_cost) <= 1e-12 * hs.final_cost
     g.close(); he.close()
+
+
+def _rccl_worker(rank, world, port, out):
+    """one process per GPU: the built-in RCCL hook (cvx_rccl_*) under a view-sharded solve"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # only carries the 128-byte RCCL id
+    import cvx_amd
+    from cvx_amd import capi
+    L = capi.lib()
+    ident = C.create_string_buffer(capi.RCCL_ID_BYTES)
+    if rank == 0:
+        capi.check(L.cvx_rccl_unique_id(ident), "unique id")
+    t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).clone()
+    dist.broadcast(t, 0)
+    ident = C.create_string_buffer(capi.RCCL_ID_BYTES)
+    ident.raw = bytes(t.tolist())
+    comm = C.c_void_p()
+    capi.check(L.cvx_rccl_create(rank, world, ident, rank, C.byref(comm)), "rccl create")
+    d = cvx_amd.synth_calib(2, 9, 12, 9, 77, ragged=5)
+    first = cvx_amd.partition_views(d["view_off"], world)
+    sh = cvx_amd.shard_calib(d, first, rank)
+    g = cvx_amd.Calib(sh["cam_of_view"], sh["view_off"], sh["point_id"], sh["obs_x"], sh["obs_y"], d["C"], d["P"], device=rank)
+    g.set_exchange(C.cast(L.cvx_rccl_allreduce, C.c_void_p).value, rank, world, device_buffers=True, ctx=comm)
+    g.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
+    s = g.solve(capi.options("refine"))
+    intr, poses, pts = g.get_params()
+    out[rank] = {"it": s.iterations, "term": s.termination, "cost": s.final_cost, "trace": s.trace()["cost"].tolist(),
+                 "intr": intr.tolist(), "pts": pts.tolist(), "poses": poses.tolist()}
+    g.close()
+    L.cvx_rccl_destroy(comm)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gpus_rccl_solve_equals_single_rank():
+    """world 2 over RCCL, one GPU per rank; skipped on a one-GPU box (the driver's 8-GPU node runs it)"""
+    import cvx_amd
+    from cvx_amd import capi
+    if capi.lib().cvx_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    d = cvx_amd.synth_calib(2, 9, 12, 9, 77, ragged=5)
+    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    s = g.solve(capi.options("refine"))
+    intr, poses, pts = g.get_params()
+    g.close()
+    r0, r1 = out[0], out[1]
+    assert r0["intr"] == r1["intr"] and r0["pts"] == r1["pts"] and r0["trace"] == r1["trace"]
+    assert (r0["it"], r0["term"]) == (s.iterations, s.termination)
+    tr = np.array(r0["trace"])
+    assert np.all(np.abs(tr - s.trace()["cost"]) <= 1e-10 * tr)
+    assert np.max(np.abs(np.array(r0["intr"]) - intr) / np.maximum(np.abs(intr), 1e-3)) < 1e-9
+    got_poses = np.concatenate([np.array(r0["poses"]), np.array(r1["poses"])])
+    assert np.max(np.abs(got_poses - poses)) < 1e-8 * np.max(np.abs(poses))
 
 
 def test_builtin_rccl_hook_single_rank():

@@ -1,6 +1,7 @@
 """GPU: the whole `bench.py --gpus 2` flow, two ranks sharing cuda:0 (CVX_BENCH_REHEARSAL=1: gloo instead of RCCL,
 the device-buffer hook summed through the host).  Checks the contract of the N > 1 run -- one JSON line from rank 0,
-weak scaling, both ranks' work counted -- not its speed.  (Collected late on purpose: it starts two more processes.)"""
+strong scaling by default (one config-4 problem over both ranks) and weak scaling on request, all ranks' work
+counted -- not its speed.  (Collected late on purpose: it starts two more processes.)"""
 import json
 import os
 import socket
@@ -14,20 +15,35 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_bench_line():
+def _run(scaling):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, CVX_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--scaling", scaling]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=100)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                      # rank 0 alone reports
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == scaling
     assert d["unit"] == "observations/s" and d["value"] > 0 and d["higher_is_better"] is True
-    # value = the observations of BOTH ranks x iterations / the slowest rank's time
-    per_rank = d["config"]["observations_per_gpu"]
-    assert abs(d["value"] - 2 * per_rank * 4 / (d["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * d["value"]
     assert "cpu_baseline" not in d              # rank 0 at N = 1 only
+    return d
+
+
+def test_two_rank_bench_line_strong_scaling():
+    """the default: ONE config-4 problem (1 080 000 observations) cut by view over the two ranks"""
+    d = _run("strong")
+    assert d["config"]["observations_total"] == 1080000
+    assert d["config"]["observations_rank0"] == 540000 and d["config"]["views_rank0"] == 5000
+    # value = the whole problem's observations x iterations / the slowest rank's time
+    assert abs(d["value"] - 1080000 * 4 / (d["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * d["value"]
+    # the sharded solve walks the same path as the single-GPU one: same accepted steps, same cost to ~1e-10
+    assert d["config"]["accepted_steps_in_last_solve"] >= 1
+
+
+def test_two_rank_bench_line_weak_scaling():
+    d = _run("weak")
+    assert d["config"]["observations_total"] == 2 * 1080000 and d["config"]["observations_rank0"] == 1080000
+    assert abs(d["value"] - 2 * 1080000 * 4 / (d["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * d["value"]
