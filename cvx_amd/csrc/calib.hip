@@ -85,7 +85,7 @@ struct cvx_calib {
     double *d_best = nullptr;        // intr | points | poses of the lowest-cost point (non-monotonic runs)
     // device: damped reduced solve (solve_kernels.h)
     int npad = 32, nT = 1;
-    double *d_A = nullptr, *d_L = nullptr, *d_s2sh = nullptr, *d_Ds = nullptr, *d_delta_s = nullptr;
+    double *d_A = nullptr, *d_s2sh = nullptr, *d_Ds = nullptr, *d_delta_s = nullptr;
     int *d_fail = nullptr;
     size_t fin_lds = 0;
     std::vector<double> s2_shared, h_tail, h_A;
@@ -110,7 +110,7 @@ cvx_calib::~cvx_calib() {
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
-                    d_E2, d_eval, d_best, d_A, d_L, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X};
+                    d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -422,29 +422,23 @@ private:
                 h->h_A.resize((size_t)tot);
                 CVX_HIP(hipMemcpyAsync(h->h_A.data(), h->d_A, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             }
-            for (int k = 0; k < h->nT; ++k) {
-                const int ntr = h->nT - 1 - k;
-                const int blocks = std::max(1, ntr * (ntr + 1) / 2);
-                hipLaunchKernelGGL(cvxs::k_chol_step, dim3(blocks), dim3(256), 0, h->stream, h->d_A, h->d_L, h->npad, ns, k,
-                                   h->nT, h->d_fail);
-            }
+            for (int k = 0; k < h->nT; ++k)
+                hipLaunchKernelGGL(cvxs::k_chol_step, dim3(cvxs::chol_step_blocks(h->nT, k)), dim3(256), 0, h->stream, h->d_A,
+                                   h->npad, ns, k, h->nT, h->d_fail, h->d_delta_s);
             CVX_HIP(hipGetLastError());
         }
         {
             cvxs::FinishArgs f;
-            f.L = h->d_L; f.ld = h->npad; f.n = ns; f.npad = h->npad;
+            f.n = ns;
             f.E = h->d_E; f.E_scal = (long long)h->E_scal; f.nranks = h->nranks; f.Ds = h->d_Ds; f.fail = h->d_fail;
             f.C = h->C; f.P = h->P; f.ncf = h->ncf; f.fix_k3 = h->fix_k3; f.cam_free = h->cam_free; f.pts_free = h->pts_free;
             f.ZC = h->ZC; f.camcol0 = h->camcol0; f.ycol = h->ycol;
             f.intr = h->d_intr[h->cur]; f.points = h->d_points[h->cur];
             f.intr_cand = h->d_intr[nxt]; f.points_cand = h->d_points[nxt];
             f.ds_emb = h->d_ds_emb; f.delta_s = h->d_delta_s; f.R = h->d_E2;
-            if (ns <= cvxs::FIN_UPD + cvxs::TB) {
-                CVX_HIP(hipFuncSetAttribute((const void *)cvxs::k_solve_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fin_lds));
-                hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(cvxs::FIN_THREADS), h->fin_lds, h->stream, f);
-            } else {
-                hipLaunchKernelGGL(cvxs::k_solve_finish_wide, dim3(1), dim3(256), h->fin_lds, h->stream, f);
-            }
+            if (h->fin_lds > 64 * 1024)
+                CVX_HIP(hipFuncSetAttribute((const void *)cvxs::k_step_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fin_lds));
+            hipLaunchKernelGGL(cvxs::k_step_finish, dim3(1), dim3(cvxs::FIN_THREADS), h->fin_lds, h->stream, f);
             CVX_HIP(hipGetLastError());
         }
         ph_end(h, PH_SOLVE);
@@ -718,16 +712,14 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     // damped reduced solve: (ns + 1) rows (the right-hand side rides as row ns), padded to 32-tiles
     h->nT = (h->ns + 1 + cvxs::TB - 1) / cvxs::TB;
     h->npad = h->nT * cvxs::TB;
-    CVX_TRY(dev_alloc(&h->d_A, (size_t)h->npad * h->npad));
-    CVX_TRY(dev_alloc(&h->d_L, (size_t)h->npad * h->npad));
-    CVX_HIP(hipMemsetAsync(h->d_L, 0, (size_t)h->npad * h->npad * sizeof(double), s));
+    // + npad extra rows below: the identity block whose elimination yields the solution (k_chol_step); never initialised
+    CVX_TRY(dev_alloc(&h->d_A, 2 * (size_t)h->npad * h->npad));
     CVX_TRY(dev_alloc(&h->d_s2sh, (size_t)std::max(1, h->ns)));
     CVX_TRY(dev_alloc(&h->d_Ds, (size_t)std::max(1, h->ns)));
     CVX_HIP(hipMemsetAsync(h->d_Ds, 0, (size_t)std::max(1, h->ns) * sizeof(double), s));
     CVX_TRY(dev_alloc(&h->d_delta_s, (size_t)std::max(1, h->ns)));
     CVX_TRY(dev_alloc(&h->d_fail, 1));
-    h->fin_lds = sizeof(double) * (h->ns <= cvxs::FIN_UPD + cvxs::TB ? cvxs::finish_lds_doubles(h->npad)
-                                                                      : (size_t)h->npad + cvxs::TB * (cvxs::TB + 1) + 8 * cvxs::TB + 256);
+    h->fin_lds = sizeof(double) * cvxs::finish_lds_doubles(h->ns);
 #undef CVX_TRY
     h->s2_shared.assign((size_t)std::max(1, h->ns), 1.0);
     CVX_HIP(hipMemcpyAsync(h->d_s2sh, h->s2_shared.data(), sizeof(double) * std::max(1, h->ns), hipMemcpyHostToDevice, s));

@@ -5,10 +5,13 @@
 // D = clamp(diag) / radius, then a linear solve) and what levmar does at
 // /root/reference/modules/util/src/3rdparty/levmar/lm_core.c:290-305 (augment the diagonal by mu,
 // solve); the factorisation is a tiled right-looking Cholesky (32 x 32 tiles, one launch per tile
-// column, trailing update on fp64 MFMA), the right-hand side rides along as an extra matrix row so
-// the forward substitution costs nothing, and one workgroup finishes: back substitution, candidate
-// shared parameters, the embedded step the pose back-substitution multiplies by, and the scalars of
-// the step (model change, norms).  Nothing in the iteration returns to the host in between.
+// column, trailing update on fp64 MFMA).  Neither substitution exists as a pass of its own: the
+// right-hand side rides along as an extra matrix row (forward substitution), and the identity rides
+// along as a block of extra rows BELOW it -- what the elimination leaves in the right-hand side's
+// column of those rows is -x L_nn, the solution itself (see k_chol_step).  One small workgroup then
+// makes the candidate shared parameters, the embedded step the pose back-substitution multiplies
+// by, and the scalars of the step (model change, norms).  Nothing in the iteration returns to the
+// host in between.
 // Included only by calib.hip.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -135,34 +138,64 @@ __device__ __forceinline__ void chol_columns(double (&row)[TB], const double (*D
 }
 
 // -----------------------------------------------------------------------------------------
-// One tile column k of the factorisation.  Block b owns trailing tile (ti, tj), k < tj <= ti.
+// One tile column k of the factorisation.  A block owns one trailing tile (ti, tj), k < tj.
 // Waves 0 and 1 each run the left-looking column loop over 64 rows: lanes 0..31 hold the rows of
 // the diagonal tile A_kk (factored redundantly by both waves and by every block: it is the serial
 // part either way), lanes 32..63 the rows of the panel tile A_ik (wave 0) or A_jk (wave 1) -- a
 // panel row obeys the same recurrence L[r][j] = (A[r][j] - sum_{m<j} L[r][m] L[j][m]) / L[j][j], so
 // the triangular solve rides along for free.  Then all four waves update A_ij -= L_ik L_jk^T with
-// MFMA.  Panel k of A is only read in this launch; factor tiles go to the separate array L (block
-// 0 the diagonal tile, the blocks with tj == k + 1 their L_ik): no block reads what another writes.
+// MFMA.  Panel k of A is only read in this launch: no block reads what another writes.
 // Rows with global index >= n (the right-hand-side row and the padding) need no special case: k_damp_prepare
 // gives them diagonal 1e300 and 1.
+//
+// The solution without a back substitution.  Below the npad rows of the matrix lie npad EXTRA rows that
+// start as the identity: extra row tile r holds I in tile column r and zeros elsewhere.  They are panel rows
+// like any other (never pivots), so after columns 0 .. m-1 are eliminated tile (r', m) holds a block of
+// L^-T, and the trailing updates accumulate, in the right-hand side's own column n (the one with the 1e300
+// pivot), -sum_k (L^-T)[r][k] y[k] = -x_r.  The ride-along division of that column by L_nn is undone when the
+// last launch writes x.  Extra tile (r', j) takes part from launch k = r on (before that it is all zero), and
+// launch r synthesises its initial value instead of loading it, so the extra rows are never initialised in
+// memory; the blocks of extra tiles sit behind the symmetric ones: rows r <= k, columns j > k.  The last
+// launch (k = nT - 1) has one block per extra row tile: ride-along only, then x_r = -L[r][n] L_nn.
+// A: (2 npad) x ld, rows >= npad the extra rows.  x_out: n doubles.
 // -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld, int n, int k, int nT, int *fail) {
+__host__ __device__ inline int chol_step_blocks(int nT, int k) {
+    const int ntr = nT - 1 - k;
+    return ntr > 0 ? ntr * (ntr + 1) / 2 + (k + 1) * ntr : nT;
+}
+
+__global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int n, int k, int nT, int *fail, double *x_out) {
     __shared__ double D[2][TB][TB + 1];
     __shared__ double P[2][TB][TB + 1];
     __shared__ double X[2][64][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     CSTAMP(0);
     const int ntr = nT - 1 - k;
-    int ti = -1, tj = -1;
+    // task: (ti, tj) tile rows of the two panels; tj < 0: no trailing tile (last launch); fresh: extra row tile k,
+    // whose tiles still have their initial values (identity in column k, zero right of it)
+    int ti, tj = -1;
+    bool fresh = false;
     if (ntr > 0) {
-        int rem = blockIdx.x, r = 0;
-        while (rem > r) { rem -= r + 1; ++r; }
-        ti = k + 1 + r; tj = k + 1 + rem;
+        const int nsym = ntr * (ntr + 1) / 2;
+        int b = blockIdx.x;
+        if (b < nsym) {
+            int r = 0;
+            while (b > r) { b -= r + 1; ++r; }
+            ti = k + 1 + r; tj = k + 1 + b;
+        } else {
+            b -= nsym;
+            const int r = b / ntr;
+            ti = nT + r; tj = k + 1 + b % ntr;
+            fresh = (r == k);
+        }
+    } else {
+        ti = nT + blockIdx.x;
+        fresh = ((int)blockIdx.x == k);
     }
     // this wave's 16x16 block of A_ij, fetched now so the latency hides behind the factorisation
     const int bi = wave >> 1, bj = wave & 1, kq = lane >> 4, cq = lane & 15;
     double a_old[4] = {0.0, 0.0, 0.0, 0.0};
-    if (ti >= 0) {
+    if (tj >= 0 && !fresh) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) a_old[q] = A[(size_t)(ti * TB + bi * 16 + kq + 4 * q) * ld + tj * TB + bj * 16 + cq];
     }
@@ -172,8 +205,8 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 256 * q, r = e >> 5, c = e & 31;
             vd[q] = A[(size_t)(k * TB + r) * ld + k * TB + c];
-            vi[q] = (ti >= 0) ? A[(size_t)(ti * TB + r) * ld + k * TB + c] : 0.0;
-            vj[q] = (ti >= 0) ? A[(size_t)(tj * TB + r) * ld + k * TB + c] : 0.0;
+            vi[q] = fresh ? ((r == c) ? 1.0 : 0.0) : A[(size_t)(ti * TB + r) * ld + k * TB + c];
+            vj[q] = (tj >= 0) ? A[(size_t)(tj * TB + r) * ld + k * TB + c] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -227,21 +260,17 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
             }
         }
         chol_columns<16>(row, Dw, mine, lane, bad);
-        if (wave == 0 && __any(bad) && lane == 0) *fail = 1;
+        if (wave == 0 && blockIdx.x == 0 && __any(bad) && lane == 0) *fail = 1;
     }
     __syncthreads();
     CSTAMP(2);
-    if (blockIdx.x == 0)
-        for (int e = tid; e < TB * TB; e += 256) {
-            const int r = e >> 5, c = e & 31;
-            L[(size_t)(k * TB + r) * ld + k * TB + c] = (c <= r) ? D[0][r][c] : 0.0;
-        }
-    if (ti < 0) return;
-    if (tj == k + 1)
-        for (int e = tid; e < TB * TB; e += 256) {
-            const int r = e >> 5, c = e & 31;
-            L[(size_t)(ti * TB + r) * ld + k * TB + c] = P[0][r][c];
-        }
+    if (tj < 0) {
+        // last launch: extra row tile r = blockIdx.x rode along as panel 0.  Column nl of it holds
+        // (-x_r) / L_nn, L_nn = D[nl][nl]
+        const int nl = n - k * TB, r0 = (int)blockIdx.x * TB;
+        if (tid < TB && r0 + tid < n) x_out[r0 + tid] = -(P[0][tid][nl] * D[0][nl][nl]);
+        return;
+    }
     // A_ij -= L_ik L_jk^T: wave w owns the 16x16 block (w >> 1, w & 1)
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -254,17 +283,16 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, double *L, int ld,
 }
 
 // -----------------------------------------------------------------------------------------
-// Finish (one workgroup): back substitution L^T x = y with y = row n of L, then everything the
-// step needs from delta_s = x:
-//   delta_s, candidate intrinsics / points, ds_emb[C][ZC] (per camera: the step laid out in Z's
+// Finish (one workgroup): everything the step needs from delta_s = x, which the last k_chol_step launch left
+// in delta_s:
+//   candidate intrinsics / points, ds_emb[C][ZC] (per camera: the step laid out in Z's
 //   column order with 1 in the gradient column), and R[4..14]:
 //   R[4] sum ds (Ds ds - gs)   R[5] |ds|^2   R[6] |x|^2 over non-constant shared blocks (Ceres)
 //   R[7] |x|^2 over free shared scalars (levmar)   R[8] 1 if the factorisation failed or ds is not finite
 //   R[9] max |gs|  R[10] max diag U  R[11] sum r^2  R[12] bad pose blocks  R[13] max |g_pose|  R[14] max diag V
 // -----------------------------------------------------------------------------------------
 struct FinishArgs {
-    const double *L;
-    int ld, n, npad;
+    int n;
     const double *E;        // S | gred | gs | diagU | scalars at E_scal
     long long E_scal;
     int nranks;
@@ -273,9 +301,6 @@ struct FinishArgs {
     int C, P, ncf, fix_k3, cam_free, pts_free, ZC, camcol0, ycol;
     const double *intr, *points;
     double *intr_cand, *points_cand, *ds_emb, *delta_s, *R;
-#ifdef CVX_STAMPS
-    long long *stamps;
-#endif
 };
 
 // block reductions of the finish kernel: wave butterflies, then four partials through LDS
@@ -360,208 +385,16 @@ __device__ __forceinline__ void finish_tail(const FinishArgs &a, const double *x
     }
 }
 
-constexpr int FIN_THREADS = 512;                 // wave 0 solves, waves 1-7 stream L and apply it
-constexpr int FIN_UPD = FIN_THREADS - 64;        // one updater thread per column: n <= FIN_UPD + 32
-constexpr int FIN_TILE = TB * (TB + 1);
-__host__ __device__ inline size_t finish_lds_doubles(int npad) { return (size_t)npad + 6 * FIN_TILE + 64; }
+constexpr int FIN_THREADS = 512;
 
-// Back substitution L^T x = y (y = row n of L, left there by the forward elimination) and the step's scalars, one
-// workgroup.  Tile row T of L (rows 32T.., columns 0..32T+31) is used three ways, all fetched ahead of need:
-//   * its diagonal tile and the tile left of it go through LDS (three rotating buffers, loaded two steps early)
-//     to wave 0, which solves the 32 unknowns of tile T and applies them to the NEXT tile's right-hand side --
-//     the only work on the critical path;
-//   * every other column belongs to one updater thread, which loads its 32 entries of tile row T while tile T is
-//     being solved and applies them one step later, while wave 0 is already solving tile T-1.
-__global__ void __launch_bounds__(FIN_THREADS) k_solve_finish(FinishArgs a) {
+__global__ void __launch_bounds__(FIN_THREADS) k_step_finish(FinishArgs a) {
     extern __shared__ double sm[];
-    double *xs = sm;                       // [npad]
-    double *bufs = xs + a.npad;            // 3 x { diag tile [32][33], left tile [32][33] }
-    double *red = bufs + 6 * FIN_TILE;     // [64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = a.n, ld = a.ld;
-    for (int i = tid; i < a.npad; i += FIN_THREADS) xs[i] = (i < n) ? a.L[(size_t)n * ld + i] : 0.0;
-#ifdef CVX_STAMPS
-    int sti = 0;
-#define STAMP() do { if (tid == 0) a.stamps[sti++] = wall_clock64(); } while (0)
-#else
-#define STAMP() do {} while (0)
-#endif
-    STAMP();
-    const int nTn = (n + TB - 1) / TB;
-    const int u = tid - 64;                // updater index = column it owns
-    // element e (0..2047) of the two LDS tiles of tile row T: e < 1024 diagonal tile, else the tile left of it
-    auto tile_src = [&](int T, int e) -> double {
-        const int half = e >> 10, r = (e >> 5) & 31, c = e & 31;
-        const int col = (T - half) * TB + c;
-        return (T >= 0 && col >= 0) ? a.L[(size_t)(T * TB + r) * ld + col] : 0.0;
-    };
-    auto tile_dst = [&](int T, int e) -> double * {
-        const int half = e >> 10, r = (e >> 5) & 31, c = e & 31;
-        return bufs + (size_t)(((T % 3) + 3) % 3) * 2 * FIN_TILE + half * FIN_TILE + r * (TB + 1) + c;
-    };
-    double hold[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old[TB], cur[TB];
-#pragma unroll
-    for (int c = 0; c < TB; ++c) { old[c] = 0.0; cur[c] = 0.0; }
-    if (wave > 0) {
-        // prologue: the last tile row's LDS tiles directly, the one above it into `hold`
-        for (int e = u; e < 2048; e += FIN_UPD) *tile_dst(nTn - 1, e) = tile_src(nTn - 1, e);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { const int e = u + FIN_UPD * q; if (e < 2048) hold[q] = tile_src(nTn - 2, e); }
-    }
+    double *xs = sm;                       // [n]
+    double *red = xs + ((a.n + 7) & ~7);   // [64]
+    for (int i = threadIdx.x; i < a.n; i += FIN_THREADS) xs[i] = a.delta_s[i];
     __syncthreads();
-    // one step; `use` = this thread's column of tile row kt+1 (fetched a step ago), `get` receives tile row kt.
-    // The barrier waits for LDS traffic only: the global loads into `get` and `hold` stay in flight across it.
-    auto step = [&](int kt, double (&use)[TB], double (&get)[TB]) {
-        if (wave == 0) {
-            const double *tile = bufs + (size_t)(kt % 3) * 2 * FIN_TILE;
-            const int m = lane & 31;
-            const double invm = 1.0 / tile[m * (TB + 1) + m];
-            double rhs = xs[kt * TB + m] * invm;        // lane m carries rhs_m / L_mm
-            // w[c] = L[c][m] / L_mm: x_c = rhs(lane c) once every c' > c has been eliminated
-            double w[TB];
-#pragma unroll
-            for (int c = 0; c < TB; ++c) w[c] = tile[c * (TB + 1) + m] * invm;
-#pragma unroll
-            for (int c = TB - 1; c > 0; --c) {
-                const double xc = readlane_f64(rhs, c);
-                if (m < c) rhs = fma(-w[c], xc, rhs);
-            }
-            if (lane < 32) xs[kt * TB + m] = rhs;
-        } else {
-            // (1) LDS tiles of tile row kt-1 (loaded during the previous step), then start fetching those of kt-2
-            if (kt >= 1) {
-#pragma unroll
-                for (int q = 0; q < 5; ++q) { const int e = u + FIN_UPD * q; if (e < 2048) *tile_dst(kt - 1, e) = hold[q]; }
-            }
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { const int e = u + FIN_UPD * q; if (e < 2048) hold[q] = tile_src(kt - 2, e); }
-            // (2) this thread's column of tile row kt, for the next step (columns left of tile kt-1 only)
-            if (u < (kt - 1) * TB) {
-                const double *Lc = a.L + (size_t)(kt * TB) * ld + u;
-#pragma unroll
-                for (int c = 0; c < TB; ++c) get[c] = Lc[(size_t)c * ld];
-            }
-            // (3) apply tile row kt+1 now that x of tile kt+1 is known
-            if (kt + 1 < nTn && u < kt * TB) {
-                const double *xk = xs + (kt + 1) * TB;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-                for (int c = 0; c < TB; c += 4) {
-                    s0 += use[c] * xk[c];
-                    s1 += use[c + 1] * xk[c + 1];
-                    s2 += use[c + 2] * xk[c + 2];
-                    s3 += use[c + 3] * xk[c + 3];
-                }
-                xs[u] -= (s0 + s1) + (s2 + s3);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        STAMP();
-        if (wave == 0 && kt >= 1) {
-            // right-hand side of tile kt-1: remove the unknowns just found (lanes 32-63 take the upper 16 of them)
-            const double *left = bufs + (size_t)(kt % 3) * 2 * FIN_TILE + FIN_TILE;
-            const int m = lane & 31, c0 = (lane >> 5) * 16;
-            const double *xk = xs + kt * TB;
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int c = 0; c < 16; c += 2) {
-                s0 += left[(c0 + c) * (TB + 1) + m] * xk[c0 + c];
-                s1 += left[(c0 + c + 1) * (TB + 1) + m] * xk[c0 + c + 1];
-            }
-            double sacc = s0 + s1;
-            sacc += __shfl_xor(sacc, 32, 64);
-            if (lane < 32) xs[(kt - 1) * TB + m] -= sacc;
-        }
-    };
-    for (int kt = nTn - 1; kt >= 0; kt -= 2) {
-        step(kt, old, cur);
-        if (kt >= 1) step(kt - 1, cur, old);
-    }
-    __syncthreads();
-    STAMP();
     finish_tail<FIN_THREADS>(a, xs, red);
 }
-
-// general form for reduced systems wider than FIN_UPD + 32 unknowns: one tile at a time, no look-ahead
-__global__ void __launch_bounds__(256) k_solve_finish_wide(FinishArgs a) {
-    extern __shared__ double sm[];
-    double *xs = sm;                       // [npad]
-    double *tile = xs + a.npad;            // [32][33]
-    double *red = tile + TB * (TB + 1);    // [256]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = a.n, ld = a.ld;
-    for (int i = tid; i < a.npad; i += 256) xs[i] = (i < n) ? a.L[(size_t)n * ld + i] : 0.0;
-#ifdef CVX_STAMPS
-    int sti = 0;
-#define STAMP() do { if (tid == 0) a.stamps[sti++] = wall_clock64(); } while (0)
-#else
-#define STAMP() do {} while (0)
-#endif
-    STAMP();
-    const int nTn = (n + TB - 1) / TB;
-    // right-looking back substitution L^T x = y, one 32-tile at a time from the bottom; the next
-    // diagonal tile is fetched into registers while the current one is being solved
-    double tnext[4] = {0.0, 0.0, 0.0, 0.0};
-    if (nTn > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + 256 * q;
-            tnext[q] = a.L[(size_t)((nTn - 1) * TB + (e >> 5)) * ld + (nTn - 1) * TB + (e & 31)];
-        }
-    }
-    __syncthreads();
-    for (int kt = nTn - 1; kt >= 0; --kt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + 256 * q;
-            tile[(e >> 5) * (TB + 1) + (e & 31)] = tnext[q];
-        }
-        if (kt > 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = tid + 256 * q;
-                tnext[q] = a.L[(size_t)((kt - 1) * TB + (e >> 5)) * ld + (kt - 1) * TB + (e & 31)];
-            }
-        }
-        __syncthreads();
-        STAMP();
-        if (wave == 0) {
-            const int m = lane & 31;
-            const double invm = 1.0 / tile[m * (TB + 1) + m];
-            double rhs = xs[kt * TB + m] * invm;        // lane m carries rhs_m / L_mm
-            // w[c] = L[c][m] / L_mm: x_c = rhs(lane c) once every c' > c has been eliminated
-            double w[TB];
-#pragma unroll
-            for (int c = 0; c < TB; ++c) w[c] = tile[c * (TB + 1) + m] * invm;
-#pragma unroll
-            for (int c = TB - 1; c > 0; --c) {
-                const double xc = readlane_f64(rhs, c);
-                if (m < c) rhs = fma(-w[c], xc, rhs);
-            }
-            if (lane < 32) xs[kt * TB + m] = rhs;
-        }
-        __syncthreads();
-        STAMP();
-        // xs[j] -= sum_c L[kt*32 + c][j] x[kt*32 + c] for every column j left of this tile
-        for (int j = tid; j < kt * TB; j += 256) {
-            const double *Lc = a.L + (size_t)(kt * TB) * ld + j;
-            double lv[TB];
-#pragma unroll
-            for (int c = 0; c < TB; ++c) lv[c] = Lc[(size_t)c * ld];     // all 32 loads in flight together
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int c = 0; c < TB; c += 4) {
-                s0 += lv[c] * xs[kt * TB + c];
-                s1 += lv[c + 1] * xs[kt * TB + c + 1];
-                s2 += lv[c + 2] * xs[kt * TB + c + 2];
-                s3 += lv[c + 3] * xs[kt * TB + c + 3];
-            }
-            xs[j] -= (s0 + s1) + (s2 + s3);
-        }
-        __syncthreads();
-        STAMP();
-    }
-    finish_tail<256>(a, xs, red);
-}
+__host__ __device__ inline size_t finish_lds_doubles(int n) { return (size_t)((n + 7) & ~7) + 64; }
 
 }  // namespace cvxs

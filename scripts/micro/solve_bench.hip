@@ -27,23 +27,18 @@ int main(int argc, char **argv) {
     std::vector<double> ones(n, 1.0);
     CK(hipMalloc(&dE, E.size() * 8)); CK(hipMemcpy(dE, E.data(), E.size() * 8, hipMemcpyHostToDevice));
     CK(hipMalloc(&ds2, n * 8)); CK(hipMemcpy(ds2, ones.data(), n * 8, hipMemcpyHostToDevice));
-    CK(hipMalloc(&dA, (size_t)npad * npad * 8)); CK(hipMalloc(&dL, (size_t)npad * npad * 8)); CK(hipMemset(dL, 0, (size_t)npad * npad * 8));
+    CK(hipMalloc(&dA, 2 * (size_t)npad * npad * 8)); CK(hipMemset(dA, 0xff, 2 * (size_t)npad * npad * 8)); dL = nullptr;
     CK(hipMalloc(&dDs, n * 8)); CK(hipMalloc(&dintr, 9 * C * 8)); CK(hipMalloc(&dpts, 3 * P * 8)); CK(hipMalloc(&dic, 9 * C * 8)); CK(hipMalloc(&dpc, 3 * P * 8));
     CK(hipMemset(dintr, 0, 9 * C * 8)); CK(hipMemset(dpts, 0, 3 * P * 8));
     CK(hipMalloc(&demb, (size_t)C * ZC * 8)); CK(hipMalloc(&ddelta, n * 8)); CK(hipMalloc(&dR, 16 * 8)); CK(hipMalloc(&dfail, 4));
     hipEvent_t ev[4]; for (int i = 0; i < 4; ++i) CK(hipEventCreate(&ev[i]));
     cvxs::DampArgs da{dE, nullptr, ds2, n, npad, 1e-4, 0.0, 1e-6, 1e32, dA, dDs};
     cvxs::FinishArgs f{};
-    f.L = dL; f.ld = npad; f.n = n; f.npad = npad; f.E = dE; f.E_scal = (long long)n * n + 3 * n; f.nranks = 1; f.Ds = dDs; f.fail = dfail;
+    f.n = n; f.E = dE; f.E_scal = (long long)n * n + 3 * n; f.nranks = 1; f.Ds = dDs; f.fail = dfail;
     f.C = C; f.P = P; f.ncf = ncf; f.fix_k3 = 1; f.cam_free = 1; f.pts_free = 1; f.ZC = ZC; f.camcol0 = camcol0; f.ycol = ycol;
     f.intr = dintr; f.points = dpts; f.intr_cand = dic; f.points_cand = dpc; f.ds_emb = demb; f.delta_s = ddelta; f.R = dR;
     if (n != C * ncf + 3 * P) { f.C = 0; f.P = 0; f.pts_free = 0; f.cam_free = 0; f.ncf = 0; }
-#ifdef CVX_STAMPS
-    long long *dst; CK(hipMalloc(&dst, 8 * 256)); CK(hipMemset(dst, 0, 8 * 256)); f.stamps = dst;
-#endif
-    const bool wide = n > cvxs::FIN_UPD + cvxs::TB;
-    const size_t lds = wide ? 8 * ((size_t)npad + 32 * 33 + 8 * 32 + 256) : 8 * cvxs::finish_lds_doubles(npad);
-    if (!wide) CK(hipFuncSetAttribute((const void *)cvxs::k_solve_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = 8 * cvxs::finish_lds_doubles(n);
     float t_d = 0, t_c = 0, t_f = 0;
     const int reps = 20;
     for (int rep = 0; rep < reps + 2; ++rep) {
@@ -51,13 +46,10 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(ev[0]));
         hipLaunchKernelGGL(cvxs::k_damp_prepare, dim3((npad * npad + 255) / 256), dim3(256), 0, 0, da);
         CK(hipEventRecord(ev[1]));
-        for (int k = 0; k < nT; ++k) {
-            const int ntr = nT - 1 - k, blocks = ntr > 0 ? ntr * (ntr + 1) / 2 : 1;
-            hipLaunchKernelGGL(cvxs::k_chol_step, dim3(blocks), dim3(256), 0, 0, dA, dL, npad, n, k, nT, dfail);
-        }
+        for (int k = 0; k < nT; ++k)
+            hipLaunchKernelGGL(cvxs::k_chol_step, dim3(cvxs::chol_step_blocks(nT, k)), dim3(256), 0, 0, dA, npad, n, k, nT, dfail, ddelta);
         CK(hipEventRecord(ev[2]));
-        if (wide) hipLaunchKernelGGL(cvxs::k_solve_finish_wide, dim3(1), dim3(256), lds, 0, f);
-        else hipLaunchKernelGGL(cvxs::k_solve_finish, dim3(1), dim3(cvxs::FIN_THREADS), lds, 0, f);
+        hipLaunchKernelGGL(cvxs::k_step_finish, dim3(1), dim3(cvxs::FIN_THREADS), lds, 0, f);
         CK(hipEventRecord(ev[3]));
         CK(hipDeviceSynchronize());
         float a, b, c;
@@ -65,10 +57,6 @@ int main(int argc, char **argv) {
         if (rep >= 2) { t_d += a; t_c += b; t_f += c; }
     }
     printf("n=%d nT=%d  damp %.1f us  chol %.1f us (%.1f/step)  finish %.1f us\n", n, nT, 1e3 * t_d / reps, 1e3 * t_c / reps, 1e3 * t_c / reps / nT, 1e3 * t_f / reps);
-#ifdef CVX_STAMPS
-    { std::vector<long long> st(256); CK(hipMemcpy(st.data(), dst, 8 * 256, hipMemcpyDeviceToHost));
-      for (int i = 1; i < 256 && st[i]; ++i) printf("%lld ", (st[i] - st[i - 1]) * 10); printf(" ns\n"); }
-#endif
 #ifdef CVX_STAMPS
     { long long cs[64]; CK(hipMemcpyFromSymbol(cs, HIP_SYMBOL(cvxs::g_cstamps), sizeof cs));
       printf("chol step 3: load %lld  factor %lld  tail %lld ns\n", (cs[1]-cs[0])*10, (cs[2]-cs[1])*10, (cs[3]-cs[2])*10); }
