@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvx_amd.so")
+# (CVX_AMD_LIB: a development build of the same library, e.g. one compiled with -DK2_PROF for scripts/k2_prof.py)
+LIB_PATH = os.environ.get("CVX_AMD_LIB") or os.path.join(_HERE, "libcvx_amd.so")
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)

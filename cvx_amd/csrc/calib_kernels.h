@@ -80,8 +80,18 @@ __device__ __forceinline__ Intr load_intr(const double *__restrict__ p) {
     return in;
 }
 
+// Per-view tables and other data that a whole wave reads at one address, written by an EARLIER kernel: read through
+// the constant address space, the compiler then fetches them with scalar loads into SGPRs (one request per wave
+// instead of 64 identical lane requests, no VGPRs, and not ordered behind the vector loads in flight).  Plain
+// pointers get vector loads here, because the kernels also store through pointers the compiler cannot tell apart.
+typedef const __attribute__((address_space(4))) double *uniform_f64;
+typedef const __attribute__((address_space(4))) int *uniform_i32;
+__device__ __forceinline__ uniform_f64 as_uniform(const double *p) { return (uniform_f64)p; }
+__device__ __forceinline__ uniform_i32 as_uniform(const int *p) { return (uniform_i32)p; }
+
 // residual only (calibration.cpp:266-311)
-__device__ __forceinline__ void reproj_residual(const Intr &in, const double *__restrict__ rt, double X0, double X1,
+template <class RT>
+__device__ __forceinline__ void reproj_residual(const Intr &in, const RT rt, double X0, double X1,
                                                 double X2, double ox, double oy, double &r0, double &r1) {
     const double xc = rt[0] * X0 + rt[1] * X1 + rt[2] * X2 + rt[36];
     const double yc = rt[3] * X0 + rt[4] * X1 + rt[5] * X2 + rt[37];
@@ -97,9 +107,11 @@ __device__ __forceinline__ void reproj_residual(const Intr &in, const double *__
 }
 
 // residual + Jacobian blocks, row-major Jp[2][6], Jc[2][9], Jx[2][3]
-__device__ __forceinline__ void reproj_jacobian(const Intr &in, const double *__restrict__ rt, double X0, double X1,
+template <class RT>
+__device__ __forceinline__ void reproj_jacobian(const Intr &in, const RT rt, double X0, double X1,
                                                 double X2, double ox, double oy, double &r0, double &r1,
                                                 double (&Jp)[12], double (&Jc)[18], double (&Jx)[6]) {
+    // (no contraction in here: the functor is evaluated in plain IEEE operations, as the reference's own build does)
     const double xc = rt[0] * X0 + rt[1] * X1 + rt[2] * X2 + rt[36];
     const double yc = rt[3] * X0 + rt[4] * X1 + rt[5] * X2 + rt[37];
     const double zc = rt[6] * X0 + rt[7] * X1 + rt[8] * X2 + rt[38];
@@ -136,7 +148,7 @@ __device__ __forceinline__ void reproj_jacobian(const Intr &in, const double *__
     // G[i][j] = sum_k dR_j[i][k] X_k
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double *d = rt + 9 + 9 * j;
+        const RT d = rt + 9 + 9 * j;
         const double g0 = d[0] * X0 + d[1] * X1 + d[2] * X2;
         const double g1 = d[3] * X0 + d[4] * X1 + d[5] * X2;
         const double g2 = d[6] * X0 + d[7] * X1 + d[8] * X2;
@@ -284,6 +296,7 @@ __global__ void __launch_bounds__(256) k_cost(const int *__restrict__ view_id, c
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
 __device__ __forceinline__ bool chol6_factor(double (&A)[21]) {
+#pragma clang fp contract(fast)
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -310,6 +323,7 @@ __device__ __forceinline__ bool chol6_factor(double (&A)[21]) {
 
 // z = L^-1 w with the packed factor of chol6_factor
 __device__ __forceinline__ void chol6_forward(const double (&Lf)[21], double (&w)[6]) {
+#pragma clang fp contract(fast)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double t = w[i];
@@ -383,9 +397,9 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 #ifdef K2_PROF
         tp = clock64();
 #endif
-        const int base = a.view_off[v];
-        const int n = a.view_off[v + 1] - base;
-        const double *rt = a.rt + (size_t)v * RT_STRIDE;
+        const int base = as_uniform(a.view_off)[v];
+        const int n = as_uniform(a.view_off)[v + 1] - base;
+        const uniform_f64 rt = as_uniform(a.rt + (size_t)v * RT_STRIDE);
         const bool active = tid < n;
         double r[2] = {0.0, 0.0}, Jp[12], Jc[18], Jx[6];
         if (active) {
@@ -405,30 +419,23 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
         K2_STAMP(0);
         // ---- per-point accumulators (unique point ids inside a view: plain read-modify-write) ----
         if (active && a.pts_free) {
-            double inc[PT_ACC];
+            // pa[i] += Jc[c] Jx[b] + Jc[9 + c] Jx[3 + b] etc., as two fused multiply-adds per accumulator (x row, then y row)
+            double *pa = ALIGNED ? pacc : accpt + pid * PT_ACC;
+            if (a.cam_free) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c)
+                for (int c = 0; c < 9; ++c)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) inc[c * 3 + b] = Jc[c] * Jx[b] + Jc[9 + c] * Jx[3 + b];
-            inc[27] = Jx[0] * Jx[0] + Jx[3] * Jx[3];
-            inc[28] = Jx[0] * Jx[1] + Jx[3] * Jx[4];
-            inc[29] = Jx[0] * Jx[2] + Jx[3] * Jx[5];
-            inc[30] = Jx[1] * Jx[1] + Jx[4] * Jx[4];
-            inc[31] = Jx[1] * Jx[2] + Jx[4] * Jx[5];
-            inc[32] = Jx[2] * Jx[2] + Jx[5] * Jx[5];
-            inc[33] = Jx[0] * r[0] + Jx[3] * r[1];
-            inc[34] = Jx[1] * r[0] + Jx[4] * r[1];
-            inc[35] = Jx[2] * r[0] + Jx[5] * r[1];
-            if (ALIGNED) {
-#pragma unroll
-                for (int i = 0; i < PT_ACC; ++i)
-                    if (i >= 27 || a.cam_free) pacc[i] += inc[i];
-            } else {
-                double *pa = accpt + pid * PT_ACC;
-#pragma unroll
-                for (int i = 0; i < PT_ACC; ++i)
-                    if (i >= 27 || a.cam_free) pa[i] += inc[i];
+                    for (int b = 0; b < 3; ++b) pa[c * 3 + b] = fma(Jc[9 + c], Jx[3 + b], fma(Jc[c], Jx[b], pa[c * 3 + b]));
             }
+            pa[27] = fma(Jx[3], Jx[3], fma(Jx[0], Jx[0], pa[27]));
+            pa[28] = fma(Jx[3], Jx[4], fma(Jx[0], Jx[1], pa[28]));
+            pa[29] = fma(Jx[3], Jx[5], fma(Jx[0], Jx[2], pa[29]));
+            pa[30] = fma(Jx[4], Jx[4], fma(Jx[1], Jx[1], pa[30]));
+            pa[31] = fma(Jx[4], Jx[5], fma(Jx[1], Jx[2], pa[31]));
+            pa[32] = fma(Jx[5], Jx[5], fma(Jx[2], Jx[2], pa[32]));
+            pa[33] = fma(Jx[3], r[1], fma(Jx[0], r[0], pa[33]));
+            pa[34] = fma(Jx[4], r[1], fma(Jx[1], r[0], pa[34]));
+            pa[35] = fma(Jx[5], r[1], fma(Jx[2], r[0], pa[35]));
         }
         K2_STAMP(1);
         // ---- Gram of the staged rows on the matrix cores ----
@@ -479,7 +486,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
             dmax = fmax(dmax, d);
             gmax = fmax(gmax, fabs(gvv[i]));
             if (MODE == 0) {
-                const double s2 = a.s2pose[6 * v + i];
+                const double s2 = as_uniform(a.s2pose)[6 * v + i];
                 double c = s2 * d;
                 c = fmin(fmax(c, a.min_diag), a.max_diag);
                 Dd[i] = c * a.inv_radius / s2 + a.mu;
@@ -505,7 +512,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
                 for (int b = 0; b < 3; ++b) {
                     double w[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) w[k] = Jp[k] * Jx[b] + Jp[6 + k] * Jx[3 + b];
+                    for (int k = 0; k < 6; ++k) w[k] = fma(Jp[6 + k], Jx[3 + b], Jp[k] * Jx[b]);
                     chol6_forward(A, w);
 #pragma unroll
                     for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + 3 * pid + b] = w[i];
