@@ -21,7 +21,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RT_STRIDE = 40;    // per view: R[9] | dR/dw_j [3][9] | t[3] | pad
 constexpr int PT_ACC = 36;       // per point accumulators: Ucx[9][3] | Uxx[6] | gx[3]
-constexpr int AROW = 18;         // LDS stride (doubles) of one staged Jacobian row (16 + pad)
+constexpr int AROW = 17;         // LDS stride (doubles) of one staged Jacobian row: odd, so that the 64 lanes' row writes spread over all banks
 
 // -----------------------------------------------------------------------------------------
 // K0: per-view rotation matrix and its derivative w.r.t. the global angle-axis vector
