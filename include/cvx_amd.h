@@ -78,7 +78,11 @@ typedef struct {
     double seconds_total;                  /* wall time inside the solve */
 } cvx_lm_summary;
 
-void cvx_lm_options_refine(cvx_lm_options *o);   /* calibration.cpp:420-428 */
+/* calibration.cpp:420-428.  Deviations from what ceres::Solve does with those options (the
+ * reference holds no vectors for this loop, parity unpinned): linear solves are exact (the reference's
+ * ITERATIVE_SCHUR + SCHUR_JACOBI conjugate gradients are inexact), and use_inner_iterations is not restated.
+ * Non-monotonic steps are, including that the solve hands back the lowest-cost point it visited. */
+void cvx_lm_options_refine(cvx_lm_options *o);
 void cvx_lm_options_handeye(cvx_lm_options *o);  /* handeye.cpp:310-319 */
 void cvx_lm_options_levmar(cvx_lm_options *o);   /* lm.hpp:43-50,61 */
 
