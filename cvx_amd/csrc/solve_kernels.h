@@ -83,7 +83,7 @@ __device__ __forceinline__ void chol_columns(double (&row)[TB], const double (*D
     (void)lane;
     double tpart = row[J0];     // row[j] - sum_{J0 <= m <= j-2} L[r][m] L[j][m]
     double valprev = 0.0;
-    // The column's serial chain is eight dependent fp64 operations; a wave issues in order, so the independent
+    // The column's serial chain is a lane read, the rsqrt and five dependent fp64 operations; a wave issues in order, so the independent
     // dot-product fmas are placed by hand into the chain's stalls, one group after each link (the compiler's
     // scheduler puts them all behind the chain).  CHOL_FENCE keeps that order.
 #define CHOL_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -101,16 +101,19 @@ __device__ __forceinline__ void chol_columns(double (&row)[TB], const double (*D
                     acc[i & 3] = fma((i & 3) ? row[J0 + i] : -row[J0 + i], pl[i], acc[i & 3]);
         };
         CHOL_FENCE();
-        double t = tpart;
-        if (j > J0) t = fma(-valprev, readlane_f64(valprev, j), t);
-        const double d = readlane_f64(t, j);
-        // 1 / sqrt(d): hardware estimate + one Newton-Raphson step of third order (no special-case
+        // the pivot does not wait for the lanes' own update: d = tpart[j] - L[j][j-1]^2 from two lane reads, of which
+        // tpart[j] was ready a column ago; and 1 / sqrt(d) is never formed: val = t y0 (1 + e h) with the Newton
+        // correction e h applied to t y0, which is ready before e is
+        const double a = (j > J0) ? readlane_f64(valprev, j) : 0.0;      // L[j][j-1]
+        const double d = fma(-a, a, readlane_f64(tpart, j));
+        const double t = fma(-valprev, a, tpart);
+        // hardware estimate of 1 / sqrt(d) + one Newton-Raphson step of third order (no special-case
         // handling: d <= 0 or non-finite gives NaN, which the flag reports)
         const double y0 = __builtin_amdgcn_rsq(d);
         CHOL_FENCE();
         dots(0);
         CHOL_FENCE();
-        const double dy = -d * y0;
+        const double dy = -d * y0, ty = t * y0;
         CHOL_FENCE();
         dots(1);
         CHOL_FENCE();
@@ -118,15 +121,14 @@ __device__ __forceinline__ void chol_columns(double (&row)[TB], const double (*D
         CHOL_FENCE();
         dots(2);
         CHOL_FENCE();
-        const double ye = y0 * e, h = fma(e, 0.375, 0.5);
+        const double tye = ty * e, h = fma(e, 0.375, 0.5);
         CHOL_FENCE();
         dots(3);
         CHOL_FENCE();
-        const double ri = fma(ye, h, y0);
+        const double val = fma(tye, h, ty);     // the diagonal lane has t == d: val = sqrt(d)
         CHOL_FENCE();
         dots(4);
         CHOL_FENCE();
-        const double val = t * ri;      // the diagonal lane has t == d: val = sqrt(d)
         bad = bad || !(d > 0.0 && d < 1.7e308);
         row[j] = val;
         valprev = val;
