@@ -1315,30 +1315,30 @@ __global__ void __launch_bounds__(256) k_backsubst_cost(const double *__restrict
 // -----------------------------------------------------------------------------------------
 // final scalar reduction (single block of 1024, fixed order):
 //   E2 = { sum cost partials, sum out_view[0][.], sum out_view[1][.], sum out_view[2][.] }
-// each thread sums a strided slice, eight independent loads in flight at a time
+// each thread sums a strided slice of each array
 // -----------------------------------------------------------------------------------------
-__device__ __forceinline__ double strided_sum_1024(const double *__restrict__ p, int n) {
-    double s = 0.0;
-    int i = threadIdx.x;
-    for (; i + 7 * 1024 < n; i += 8 * 1024) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[i + u * 1024];
-        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    for (; i < n; i += 1024) s += p[i];
-    return s;
-}
-
 __global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict__ cost_partial, int n_partial,
                                                         const double *__restrict__ out_view, int V,
                                                         double *__restrict__ E2, double *__restrict__ host_copy,
                                                         double seq) {
     __shared__ double sh[4][16];
-    double s[4];
-    s[0] = strided_sum_1024(cost_partial, n_partial);
+    // the four arrays side by side, 32 loads in flight per thread and round (a single workgroup is bound by the
+    // latency of its loads: one array after the other, with a sequential remainder loop each, took twice as long)
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nmax = n_partial > V ? n_partial : V;
+    for (int base = 0; base < nmax; base += 8 * 1024) {
+        double v[4][8];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) s[k + 1] = strided_sum_1024(out_view + (size_t)k * V, V);
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + (int)threadIdx.x + u * 1024;
+            v[0][u] = i < n_partial ? cost_partial[i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k + 1][u] = i < V ? out_view[(size_t)k * V + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            s[k] += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
