@@ -135,6 +135,7 @@ SIGNATURES = {
     "cvx_toolba_create": (C.c_int, [C.POINTER(ToolBADesc), C.POINTER(C.c_void_p)]),
     "cvx_toolba_destroy": (None, [C.c_void_p]),
     "cvx_lm_options_toolba": (None, [C.POINTER(LMOptions)]),
+    "cvx_toolba_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "cvx_toolba_cost": (C.c_int, [C.c_void_p, dp, dp, dp]),
     "cvx_toolba_normal_eq": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp]),
     "cvx_toolba_solve": (C.c_int, [C.c_void_p, dp, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]),

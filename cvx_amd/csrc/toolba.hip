@@ -25,6 +25,10 @@ struct cvx_toolba {
     int *d_view = nullptr, *d_jobs = nullptr, *d_job_first = nullptr;
     double *d_trans = nullptr, *d_params = nullptr, *d_intr = nullptr, *d_partial = nullptr, *d_cpartial = nullptr, *d_out = nullptr;
     double *h_out = nullptr, *h_params = nullptr;
+    // exchange (view-sharded runs: every rank holds its own views' observations, the pose and the points are shared)
+    cvx_allreduce_fn xfn = nullptr;
+    void *xctx = nullptr;
+    int rank = 0, nranks = 1, xdev = 0;
     ~cvx_toolba() {
         (void)hipSetDevice(device);
         for (void *p : {(void *)d_obs, (void *)d_view, (void *)d_jobs, (void *)d_job_first, (void *)d_trans,
@@ -68,8 +72,11 @@ int device_cost(cvx_toolba *h, const double *x, double *cost) {
     const size_t slot = (size_t)h->P * TBA_ACC;
     hipLaunchKernelGGL(k_tba_cost_final, dim3(1), dim3(TBA_THREADS), 0, h->stream, h->d_cpartial, h->n_jobs, h->d_out + slot);
     CVX_HIP(hipGetLastError());
+    const bool sharded = h->nranks > 1 && h->xfn;
+    if (sharded && h->xdev && h->xfn(h->xctx, h->d_out + slot, 1, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
     CVX_HIP(hipMemcpyAsync(h->h_out + slot, h->d_out + slot, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
+    if (sharded && !h->xdev && h->xfn(h->xctx, h->h_out + slot, 1, 0, nullptr)) return CVX_ERR_EXCHANGE;
     *cost = 0.5 * h->h_out[slot];
     return CVX_OK;
 }
@@ -84,8 +91,14 @@ int device_blocks(cvx_toolba *h, const double *x) {
     }
     hipLaunchKernelGGL(k_tba_reduce, dim3(h->P), dim3(64), 0, h->stream, h->d_partial, h->d_job_first, h->d_out);
     CVX_HIP(hipGetLastError());
-    CVX_HIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * TBA_ACC * (size_t)h->P, hipMemcpyDeviceToHost, h->stream));
+    // the one exchange step of a linearisation: the P x 55 block sums, summed over the ranks' view shards; every
+    // rank then eliminates the points and solves the same 6 x 6 system
+    const size_t cnt = TBA_ACC * (size_t)h->P;
+    const bool sharded = h->nranks > 1 && h->xfn;
+    if (sharded && h->xdev && h->xfn(h->xctx, h->d_out, cnt, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
+    CVX_HIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
+    if (sharded && !h->xdev && h->xfn(h->xctx, h->h_out, cnt, 0, nullptr)) return CVX_ERR_EXCHANGE;
     return CVX_OK;
 }
 
@@ -362,6 +375,12 @@ extern "C" int cvx_toolba_create(const cvx_toolba_desc *d, cvx_toolba **out) {
     CVX_HIP(hipMemcpyAsync(h->d_intr, d->intrinsics, 9 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();
+    return CVX_OK;
+}
+
+extern "C" int cvx_toolba_set_exchange(cvx_toolba *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks, int device_buffers) {
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return CVX_ERR_INVALID_ARG;
+    h->xfn = fn; h->xctx = ctx; h->rank = rank; h->nranks = nranks; h->xdev = device_buffers ? 1 : 0;
     return CVX_OK;
 }
 

@@ -313,6 +313,11 @@ class ToolBA:
         except Exception:
             pass
 
+    def set_exchange(self, fn, rank, nranks, device_buffers, ctx=None):
+        self._hook = fn
+        addr = C.cast(fn, C.c_void_p) if not isinstance(fn, int) else C.c_void_p(fn)
+        check(lib().cvx_toolba_set_exchange(self.h, addr, ctx, rank, nranks, int(device_buffers)), "set_exchange")
+
     def cost(self, p, points):
         p, points = f64(p), f64(points); c = C.c_double()
         check(lib().cvx_toolba_cost(self.h, pd(p), pd(points), C.byref(c)), "cvx_toolba_cost")

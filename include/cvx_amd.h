@@ -290,6 +290,9 @@ typedef struct {
 int cvx_toolba_create(const cvx_toolba_desc *desc, cvx_toolba **out);
 void cvx_toolba_destroy(cvx_toolba *h);
 void cvx_lm_options_toolba(cvx_lm_options *o);   /* hand_eye_registration.cpp:201-210 */
+/* view-sharded runs: each rank's handle holds a range of the views (its observations and pre-transforms), pose and
+ * points are shared; one all-reduce of the n_points x 55 block sums per linearisation, one double per cost */
+int cvx_toolba_set_exchange(cvx_toolba *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks, int device_buffers);
 /* 1/2 sum rho(|r|^2), what Problem::Evaluate returns at :222 */
 int cvx_toolba_cost(cvx_toolba *h, const double p[7], const double *points, double *cost);
 /* robustified normal equations over the tangent space, as arrowhead blocks: Hpp[36], gp[6], W[n_points][6][3],

@@ -67,6 +67,21 @@ def _worker(rank, world, port, out):
     he.set_exchange(cb, rank, world, device_buffers=False)
     p, hs = he.solve(x0)
     res["he_p"] = p.tolist(); res["he_cost"] = hs.final_cost
+    # tool-level bundle adjustment shards by view: one all-reduce of the P x 55 block sums per linearisation
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_helpers import toolba_problem
+    from cvx_amd.problem import ToolBA
+    tb = toolba_problem(np.random.default_rng(5), 41, ragged=4, outliers=0.05)
+    v0, v1 = (41 * rank) // world, (41 * (rank + 1)) // world
+    o0, o1 = int(tb["view_off"][v0]), int(tb["view_off"][v1])
+    for dev in (False, True):
+        t = ToolBA(tb["view_off"][v0:v1 + 1] - o0, tb["point_id"][o0:o1], tb["obs_x"][o0:o1], tb["obs_y"][o0:o1],
+                   tb["trans"][v0:v1], tb["intr"], tb["P"])
+        t.set_exchange(cb2 if dev else cb, rank, world, device_buffers=dev)
+        pt, xt, stb = t.solve(tb["p0"], tb["points"], capi.options("toolba"))
+        res["tba_dev" if dev else "tba"] = {"p": pt.tolist(), "x": xt.tolist(), "cost": stb.final_cost, "it": stb.iterations,
+                                              "trace": list(stb.trace_cost[:stb.trace_len])}
+        t.close()
     out[rank] = res
     g.close(); he.close()
     dist.barrier()
@@ -115,6 +130,22 @@ def test_two_rank_solve_equals_single_rank():
     assert r0["he_p"] == r1["he_p"]
     assert np.max(np.abs(np.array(r0["he_p"]) - p)) < 1e-12 and abs(r0["he_cost"] - hs.final_cost) <= 1e-12 * hs.final_cost
     g.close(); he.close()
+    # tool-level bundle adjustment, host-buffer and device-buffer protocol
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_helpers import toolba_problem
+    from cvx_amd.problem import ToolBA
+    tb = toolba_problem(np.random.default_rng(5), 41, ragged=4, outliers=0.05)
+    t = ToolBA(tb["view_off"], tb["point_id"], tb["obs_x"], tb["obs_y"], tb["trans"], tb["intr"], tb["P"])
+    pt, xt, stb = t.solve(tb["p0"], tb["points"], capi.options("toolba"))
+    t.close()
+    for key in ("tba", "tba_dev"):
+        a, b = r0[key], r1[key]
+        assert a["p"] == b["p"] and a["x"] == b["x"] and a["trace"] == b["trace"]      # both ranks: the same bits
+        n = min(len(a["trace"]), stb.trace_len, 12)
+        tr1 = np.array(stb.trace_cost[:n])
+        assert np.max(np.abs(np.array(a["trace"][:n]) - tr1) / tr1) <= 1e-9
+        assert abs(a["cost"] - stb.final_cost) <= 1e-9 * stb.final_cost
+        assert np.max(np.abs(np.array(a["p"]) - pt)) <= 1e-8 and np.max(np.abs(np.array(a["x"]) - xt)) <= 1e-8
 
 
 def _rccl_worker(rank, world, port, out):
