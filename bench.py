@@ -233,8 +233,8 @@ def toolba_bench(cvx_amd, torch, device, with_cpu, V=CAMERAS * VIEWS_PER_CAMERA,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=1250, help="views per camera of the CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=10)
