@@ -165,3 +165,23 @@ def test_homography_batch_argument_checks():
     with pytest.raises(capi.CvxError) as e:
         HomographyBatch([0, 5, 3], z, z, z, z)
     assert e.value.status == capi.ERR_INVALID_ARG
+
+
+def test_lm_driver_hands_back_the_lowest_cost_point():
+    """The trust-region loop with non-monotonic steps (calibration.cpp:421) may accept an uphill step; what the solve
+    returns is the lowest-cost point it visited (documented behaviour of ceres use_nonmonotonic_steps).  Scripted
+    evaluator, host only: tests/cpp/lm_driver_test.cpp."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "lm_driver_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() (make -C cvx_amd/csrc)"
+    rows = {r["name"]: r for r in map(json.loads, subprocess.check_output([exe], timeout=60).decode().splitlines())}
+    assert all(r["status"] == 0 and r["iterations"] == 4 for r in rows.values())
+    m = rows["monotone"]
+    assert (m["final_cost"], m["at"], m["saved"], m["restored"], m["successful"]) == (60.0, 3, 0, 0, 4)
+    u = rows["uphill_then_end"]      # 50, 40, 45 (uphill, accepted), 44: back to the 40
+    assert (u["final_cost"], u["at"], u["saved"], u["restored"], u["successful"]) == (40.0, 1, 1, 1, 4)
+    r = rows["monotonic_rejects"]    # the same costs with monotonic steps: 45 and 44 are never accepted
+    assert (r["final_cost"], r["at"], r["saved"], r["restored"], r["successful"]) == (40.0, 1, 0, 0, 2)
+    b = rows["uphill_then_better"]   # a later, lower minimum makes the saved copy stale: not restored
+    assert (b["final_cost"], b["at"], b["restored"]) == (30.0, 3, 0)
