@@ -205,6 +205,7 @@ int launch_schur(cvx_calib *h) {
         K4Args q;
         q.Z = h->d_Z; q.chk_row0 = h->d_chk_row0; q.tasks = h->d_k4tasks; q.slab = h->d_slab_tile;
         q.ZC = h->ZC; q.ZCp = K4_PITCH; q.KB = K4_KB; q.n_chunks = h->n_chunks; q.nb = h->nb; q.nblk = h->nblk; q.parts = h->parts;
+        q.zero_row = 6 * h->V;      // d_Z ends in eight rows that stay zero
         CVX_HIP(hipFuncSetAttribute((const void *)k_schur_syrk4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
         hipLaunchKernelGGL(k_schur_syrk4, dim3(blocks), dim3(64 * K4_WAVES), h->k3_lds, h->stream, q);
         CVX_HIP(hipGetLastError());
@@ -588,7 +589,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     std::vector<K4Task> k4tasks;
     if (h->ZC <= K4_PITCH) {
         h->parts = k4_build_tasks(h->nb, k4tasks);
-        h->k3_lds = 2 * (size_t)K4_KB * K4_PITCH * sizeof(double) + 512;   // + slack: groups past nb are read, not used
+        h->k3_lds = K4_BUFS * (size_t)K4_KB * K4_PITCH * sizeof(double) + 512;   // + slack: groups past nb are read, not used
     }
     h->T = maxn <= 64 ? 64 : maxn <= 128 ? 128 : maxn <= 256 ? 256 : 512;
     const int W = h->T / 64;

@@ -697,6 +697,7 @@ __global__ void __launch_bounds__(64 * K3_WAVES) k_schur_syrk(K3Args a) {
 //         unused accumulator slots of DIAG task I, and the corner block (nb - 1, nb - 1) in a fifth.
 // -----------------------------------------------------------------------------------------
 constexpr int K4_WAVES = 8;
+constexpr int K4_BUFS = 2;        // stage buffers in LDS
 constexpr int K4_KB = 16;         // rows per stage
 constexpr int K4_PITCH = 400;     // LDS row pitch in doubles (16 mod 32: conflict-free operand reads); ZC <= 400
 
@@ -715,9 +716,19 @@ struct K4Args {
     const K4Task *tasks;   // [parts * K4_WAVES], nA = 0 marks an idle wave
     double *slab;          // [n_chunks][nblk][256]
     int ZC, ZCp, KB, n_chunks, nb, nblk, parts;   // ZCp, KB: informational (the kernel uses K4_PITCH, K4_KB)
+    int zero_row;          // first of the (at least two) zero rows behind Z's last row
 };
 
 #define K4_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f64_4x4x4f64(A_, B_, C_, 0, 0, 0)
+
+// one global_load_lds_dwordx4: lane l copies 16 bytes from g + OFF to LDS byte address l_base + OFF + 16 l (l_base
+// wave-uniform, in M0 for the duration of the instruction; M0 is the compiler's, so it is put back)
+template <int OFF>
+__device__ __forceinline__ void k4_glds16(const void *g, unsigned l_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(l_base), "n"(OFF) : "memory");
+}
 
 // MODE 0: FULL 4 x 4 groups; 1: DIAG, 4 groups; 2: DIAG, 4 groups + the edge group: no branch in the k loop.
 // 3 / 4: FULL / DIAG with fewer than 4 x 4 groups (tiles at the border), one scalar branch per block.
@@ -755,26 +766,28 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
 
-    // staging: K4_KB rows of ZC doubles per stage; 32 threads per row, 16 bytes each, six column slices
-    const int halfc = ZC >> 1;
-    constexpr int NLD = (K4_PITCH / 2 + 31) / 32;
-    const int srow = tid >> 5, sc = tid & 31;
+    // staging: K4_KB rows of ZC doubles per stage, copied global -> LDS by the load unit itself (global_load_lds,
+    // 16 bytes per lane: no staging registers, no ds_write pass).  One wave instruction fills 1 KB of LDS, lane l at
+    // base + 16 l, so a row goes in pieces of 1 KB and wave w copies rows 2 w and 2 w + 1.  The pieces are whole:
+    // the last one of a row runs into the next row of Z (memory that exists: Z ends in eight rows of padding) and
+    // lands in the pad columns of the LDS row, which no counted block reads.  Rows past the end of the chunk (last
+    // stage only) are copied from Z's padding rows, which are zero.  The copies are issued from inline asm: told of
+    // an LDS-DMA in flight, the compiler turns every wait for an LDS operand into lgkmcnt(0), which would stall the
+    // operand pipeline below on its newest read; the wait for the copies (vmcnt) is written out before the barrier.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nstages = (r1 - r0 + K4_KB - 1) / K4_KB;
-    double2 st[NLD];
-    auto fetch = [&](int s) {
-        const int grow = r0 + s * K4_KB + srow;
-        const double2 *g = (const double2 *)(a.Z + (size_t)grow * ZC) + sc;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    auto fetch = [&](int s, int buf) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            st[i] = double2{0.0, 0.0};
-            if (sc + 32 * i < halfc && grow < r1) st[i] = g[32 * i];
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wv + rr, grow = r0 + s * K4_KB + row;
+            const char *g = (const char *)(a.Z + (size_t)(grow < r1 ? grow : a.zero_row) * ZC) + 16 * lane;
+            const unsigned l = lds0 + 8u * (unsigned)(buf * K4_KB * K4_PITCH + row * K4_PITCH);
+            k4_glds16<0>(g, l);
+            if (ZC > 128) k4_glds16<1024>(g, l);
+            if (ZC > 256) k4_glds16<2048>(g, l);
+            if (ZC > 384 && lane < 8) k4_glds16<3072>(g, l);      // pitch 400: 128 bytes are left
         }
-    };
-    auto stash = [&](int buf) {
-        double2 *dst = (double2 *)(lds + (size_t)buf * K4_KB * K4_PITCH + srow * K4_PITCH) + sc;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (sc + 32 * i < halfc) dst[32 * i] = st[i];
     };
     auto kstep = [&](const double *p) {     // p = stage buffer + 4 ks rows
         double av[4];
@@ -810,18 +823,102 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
             }
         }
     };
-    if (nstages > 0) { fetch(0); stash(0); }
+    // Whole tiles (MODE 0..2): the stage as one pipelined instruction stream.  The two waves of a SIMD run the same
+    // code from the same barrier and share one matrix pipe in turn, so they reach every wait for an LDS operand
+    // together and stay in step: a read issued right before its use costs the pipe its whole latency, the other wave
+    // hides nothing (the form above: matrix pipe 62 % busy).  Here every operand register is read again, for its
+    // next use sixteen or more MFMAs later, right after its last use -- one or two ds_read per four MFMAs, in their
+    // issue shadow -- and the scheduling fences pin that order; the next stage is on its way into the other buffer
+    // meanwhile (fetch).  Accumulation order per output is unchanged (rows
+    // ascending): bit-identical partial sums.
+#define K4_SB() __builtin_amdgcn_sched_barrier(0)
+    auto stage_full = [&](const double *src) {
+        double A[2][4], B[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[0][i] = src[pA0 + 16 * i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B[r] = src[pBr[r]];
+        K4_SB();
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int ks = g >> 2, j = g & 3, ca = ks & 1;
+            const double *pb = src + ((g + 1) >> 2) * 4 * K4_PITCH, *pa = src + (ks + 1) * 4 * K4_PITCH;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) K4_MFMA(A[ca][i], B[r], acc[i][j][r]);
+                K4_SB();
+                // rotation r of the next column group takes the place of the one just used
+                if (g < 15) B[r] = pb[pBr[r] + 16 * ((g + 1) & 3)];
+                if (j == 2 && ks < 3) A[ca ^ 1][r] = pa[pA0 + 16 * r];
+                K4_SB();
+            }
+        }
+    };
+    auto stage_diag = [&](const double *src) {
+        double A[2][4], R[4][4], E[4];      // R[j][r]: column group a0 + j rotated by 4 r (r = 0 is A[j] itself)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[0][i] = src[pA0 + 16 * i];
+#pragma unroll
+        for (int j = 3; j >= 0; --j)
+#pragma unroll
+            for (int r = 1; r < 4; ++r) R[j][r] = src[pBr[r] + 16 * j];
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) E[r] = src[pEr[r]];
+        }
+        K4_SB();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ca = ks & 1;
+            const double *p1 = src + (ks + 1) * 4 * K4_PITCH;
+            // column groups 3, 2, 1, 0: blocks (i, j), i <= j
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int i = 0; i <= j; ++i) K4_MFMA(A[ca][i], r == 0 ? A[ca][j] : R[j][r], acc[i][j][r]);
+                    K4_SB();
+                    if (ks < 3 && r > 0) R[j][r] = p1[pBr[r] + 16 * j];
+                    if (ks < 3 && j == 1) A[ca ^ 1][r] = p1[pA0 + 16 * r];
+                    K4_SB();
+                }
+            }
+            if (MODE == 2) {
+                // free slots (1,0) (2,0) (2,1) (3,0): blocks (a0 + 0..3, edge); (3,1): the corner block
+#pragma unroll
+                for (int r = 3; r >= 0; --r) {
+                    K4_MFMA(A[ca][0], E[r], acc[1][0][r]);
+                    K4_MFMA(A[ca][1], E[r], acc[2][0][r]);
+                    K4_MFMA(A[ca][2], E[r], acc[2][1][r]);
+                    K4_MFMA(A[ca][3], E[r], acc[3][0][r]);
+                    if (has_corner) K4_MFMA(E[0], E[r], acc[3][1][r]);
+                    K4_SB();
+                    if (ks < 3) E[r] = p1[pEr[r]];
+                    K4_SB();
+                }
+            }
+        }
+    };
+    // two stage buffers: the copy of stage s + 1 runs while stage s is multiplied.  (A third buffer with the copy two
+    // stages ahead and a counted vmcnt measured the same, 136.0 against 135.3 us: the copies are not late.)
+    if (nstages > 0) fetch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
-        if (s + 1 < nstages) fetch(s + 1);
+        if (s + 1 < nstages) fetch(s + 1, (s + 1) & 1);
         const double *src = lds + (size_t)(s & 1) * K4_KB * K4_PITCH;
-        if (!GEN || nA > 0) {
+        if (!GEN) {
+            if (DIAG) stage_diag(src); else stage_full(src);
+        } else if (nA > 0) {
 #pragma unroll
             for (int ks = 0; ks < K4_KB; ks += 4) kstep(src + ks * K4_PITCH);
         }
-        if (s + 1 < nstages) stash((s + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of stage s + 1 have landed
         __syncthreads();
     }
+#undef K4_SB
     if (nA <= 0) return;
     // accumulator r of block (gA, gB), lane l: row 4b + i, column 4((b - r) & 3) + j with i = l >> 4, b = (l >> 2) & 3,
     // j = l & 3 (the rotation by 4r hands block b the B block b - r)
@@ -847,7 +944,7 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
 }
 
 __global__ void __launch_bounds__(64 * K4_WAVES, 2) k_schur_syrk4(K4Args a) {
-    extern __shared__ double lds[];      // [2][KB][ZCp]
+    extern __shared__ double lds[];      // [K4_BUFS][K4_KB][K4_PITCH]
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int part = slot % a.parts, chunk = (slot / a.parts) * 8 + xcd;

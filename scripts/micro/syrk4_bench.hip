@@ -11,7 +11,9 @@ using namespace cvxk;
 
 int main(int argc, char **argv) {
     const int ZC = argc > 1 ? atoi(argv[1]) : 336, rows = argc > 2 ? atoi(argv[2]) : 60000, want_chunks = argc > 3 ? atoi(argv[3]) : 128;
-    const int nb = ZC / 16, nblk = nb * (nb + 1) / 2, KB = 16, ZCp = ZC + ((ZC % 32 == 16) ? 0 : 16);
+    const int nb = ZC / 16, nblk = nb * (nb + 1) / 2, ZCp = ZC + ((ZC % 32 == 16) ? 0 : 16);
+    int KB = 16;
+    while (KB > 4 && KB * ZC > 6144) KB -= 4;     // as cvx_calib_create sizes the 16x16x4 kernel's stage
     std::vector<double> Z((size_t)rows * ZC);
     srand(3);
     for (auto &v : Z) v = rand() / (double)RAND_MAX - 0.5;
@@ -24,13 +26,14 @@ int main(int argc, char **argv) {
     printf("ZC=%d nb=%d nblk=%d rows=%d chunks=%d  parts: 16x16x4 %d, 4x4x4 %d (%zu tasks)\n", ZC, nb, nblk, rows, n_chunks, parts3, parts4, tasks.size());
     double *dZ, *s3, *s4; int *dr; K4Task *dt;
     const size_t slab = (size_t)n_chunks * nblk * 256;
-    CK(hipMalloc(&dZ, Z.size() * 8)); CK(hipMemcpy(dZ, Z.data(), Z.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dZ, (Z.size() + 8 * (size_t)ZC) * 8)); CK(hipMemset(dZ, 0, (Z.size() + 8 * (size_t)ZC) * 8));
+    CK(hipMemcpy(dZ, Z.data(), Z.size() * 8, hipMemcpyHostToDevice));
     CK(hipMalloc(&s3, slab * 8)); CK(hipMalloc(&s4, slab * 8)); CK(hipMemset(s3, 0, slab * 8)); CK(hipMemset(s4, 0xff, slab * 8));
     CK(hipMalloc(&dr, row0.size() * 4)); CK(hipMemcpy(dr, row0.data(), row0.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dt, tasks.size() * sizeof(K4Task))); CK(hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(K4Task), hipMemcpyHostToDevice));
-    const size_t ldsb = 2 * (size_t)KB * ZCp * 8, ldsb4 = 2 * (size_t)K4_KB * K4_PITCH * 8 + 512;
+    const size_t ldsb = 2 * (size_t)KB * ZCp * 8, ldsb4 = K4_BUFS * (size_t)K4_KB * K4_PITCH * 8 + 512;
     K3Args k3{dZ, dr, s3, ZC, ZCp, KB, n_chunks, nb, nblk, parts3};
-    K4Args k4{dZ, dr, dt, s4, ZC, ZCp, KB, n_chunks, nb, nblk, parts4};
+    K4Args k4{dZ, dr, dt, s4, ZC, ZCp, KB, n_chunks, nb, nblk, parts4, rows};
     CK(hipFuncSetAttribute((const void *)k_schur_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     CK(hipFuncSetAttribute((const void *)k_schur_syrk4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb4));
     const int g3 = 8 * ((n_chunks + 7) / 8) * parts3, g4 = 8 * ((n_chunks + 7) / 8) * parts4;
