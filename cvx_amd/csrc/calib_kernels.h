@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(64 * K3_WAVES) k_schur_syrk(K3Args a) {
 //         unused accumulator slots of DIAG task I, and the corner block (nb - 1, nb - 1) in a fifth.
 // -----------------------------------------------------------------------------------------
 constexpr int K4_WAVES = 8;
-constexpr int K4_BUFS = 2;        // stage buffers in LDS
+constexpr int K4_BUFS = 3;        // stage buffers in LDS
 constexpr int K4_KB = 16;         // rows per stage
 constexpr int K4_PITCH = 400;     // LDS row pitch in doubles (16 mod 32: conflict-free operand reads); ZC <= 400
 
@@ -707,7 +707,7 @@ struct K4Task {
     int diag;        // 1: DIAG task (b0 == a0)
     int edge;        // DIAG: column group riding in the free slots, or -1
     int corner;      // DIAG: 1 if the block (edge, edge) rides too
-    int pad;
+    int copy;        // rows of every stage this wave copies into LDS: first | count << 8 (k4_build_tasks)
 };
 
 struct K4Args {
@@ -721,13 +721,15 @@ struct K4Args {
 
 #define K4_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f64_4x4x4f64(A_, B_, C_, 0, 0, 0)
 
-// one global_load_lds_dwordx4: lane l copies 16 bytes from g + OFF to LDS byte address l_base + OFF + 16 l (l_base
-// wave-uniform, in M0 for the duration of the instruction; M0 is the compiler's, so it is put back)
+// one global_load_lds_dwordx4: lane l copies 16 bytes from g_base + v_off + OFF to LDS byte address l_base + OFF + 16 l
+// (g_base and l_base wave-uniform: the global address is a scalar base plus a 32-bit lane offset, so a copy costs no
+// vector address arithmetic; l_base sits in M0 for the duration of the instruction; M0 is the compiler's, so it is
+// put back)
 template <int OFF>
-__device__ __forceinline__ void k4_glds16(const void *g, unsigned l_base) {
+__device__ __forceinline__ void k4_glds16(const void *g_base, unsigned v_off, unsigned l_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(l_base), "n"(OFF) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v_off), "s"(g_base), "s"(l_base), "n"(OFF) : "memory");
 }
 
 // MODE 0: FULL 4 x 4 groups; 1: DIAG, 4 groups; 2: DIAG, 4 groups + the edge group: no branch in the k loop.
@@ -777,17 +779,26 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nstages = (r1 - r0 + K4_KB - 1) / K4_KB;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
-    auto fetch = [&](int s, int buf) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = 2 * wv + rr, grow = r0 + s * K4_KB + row;
-            const char *g = (const char *)(a.Z + (size_t)(grow < r1 ? grow : a.zero_row) * ZC) + 16 * lane;
-            const unsigned l = lds0 + 8u * (unsigned)(buf * K4_KB * K4_PITCH + row * K4_PITCH);
-            k4_glds16<0>(g, l);
-            if (ZC > 128) k4_glds16<1024>(g, l);
-            if (ZC > 256) k4_glds16<2048>(g, l);
-            if (ZC > 384 && lane < 8) k4_glds16<3072>(g, l);      // pitch 400: 128 bytes are left
+    // copy number idx (0..5) of a stage: row 2 wv + idx / 3 of it, piece idx % 3 (and, ZC > 384, the 128-byte rest)
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const int crow0 = t.copy & 255, crows = t.copy >> 8;      // this wave's rows of a stage (wave-uniform)
+    // piece k (0..2; with k = 2 goes, for ZC > 384, the 128-byte rest) of stage row `row`
+    auto copy_piece = [&](int s, int buf, int row, int k) {
+        const int grow = r0 + s * K4_KB + row;
+        const double *g = a.Z + (size_t)(grow < r1 ? grow : a.zero_row) * ZC;      // wave-uniform
+        const unsigned l = lds0 + 8u * (unsigned)(buf * K4_KB * K4_PITCH + row * K4_PITCH);
+        if (k == 0) k4_glds16<0>(g, lane16, l);
+        if (k == 1 && ZC > 128) k4_glds16<1024>(g, lane16, l);
+        if (k == 2 && ZC > 256) {
+            k4_glds16<2048>(g, lane16, l);
+            if (ZC > 384 && lane < 8) k4_glds16<3072>(g, lane16, l);      // pitch 400: 128 bytes are left
         }
+    };
+    // this wave's rows from `first` on, one after the other
+    auto copy_rows = [&](int s, int buf, int first) {
+        for (int i = first; i < crows; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) copy_piece(s, buf, crow0 + i, k);
     };
     auto kstep = [&](const double *p) {     // p = stage buffer + 4 ks rows
         double av[4];
@@ -823,55 +834,85 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
             }
         }
     };
-    // Whole tiles (MODE 0..2): the stage as one pipelined instruction stream.  The two waves of a SIMD run the same
+    // Whole tiles (MODE 0..2): the chunk as one pipelined instruction stream.  The two waves of a SIMD run the same
     // code from the same barrier and share one matrix pipe in turn, so they reach every wait for an LDS operand
     // together and stay in step: a read issued right before its use costs the pipe its whole latency, the other wave
-    // hides nothing (the form above: matrix pipe 62 % busy).  Here every operand register is read again, for its
-    // next use sixteen or more MFMAs later, right after its last use -- one or two ds_read per four MFMAs, in their
-    // issue shadow -- and the scheduling fences pin that order; the next stage is on its way into the other buffer
-    // meanwhile (fetch).  Accumulation order per output is unchanged (rows
-    // ascending): bit-identical partial sums.
+    // hides nothing (the k-step form above: matrix pipe 62 % busy).  Here every operand register is read again, for
+    // its next use sixteen or more MFMAs later, right after its last use -- one or two ds_read per four MFMAs, in
+    // their issue shadow -- and the scheduling fences pin that order.  Three stage buffers and ONE barrier per
+    // stage, three quarters into it, which does two things at once: every wave has waited for its own copies of
+    // stage s + 1 (issued a stage earlier), so behind the barrier that stage is complete and a wave that finishes
+    // stage s goes straight on; and every wave has left stage s - 1, so its buffer is free and the copies of stage
+    // s + 2 go there, one at a time between the MFMAs of the last quarter.  The barrier is a bare s_barrier: no wave
+    // has to drain its LDS reads for it.  Accumulation order per output is unchanged (rows ascending):
+    // bit-identical partial sums.
 #define K4_SB() __builtin_amdgcn_sched_barrier(0)
-    auto stage_full = [&](const double *src) {
+    auto stage_buf = [&](int bufi) -> const double * { return lds + (size_t)bufi * K4_KB * K4_PITCH; };
+    auto stage_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's copies of stage s + 1 have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // operand addresses of the current stage buffer (elements from lds), moved from buffer to buffer in place: an
+    // invariant copy of each next to a per-stage one is five to nine registers this kernel does not have
+    typedef const __attribute__((address_space(3))) double *lds_cptr;      // a 32-bit LDS address, as the ds_read takes it
+    const lds_cptr lbase = (lds_cptr)lds;
+    lds_cptr qA = lbase + pA0, qB[4] = {lbase + pBr[0], lbase + pBr[1], lbase + pBr[2], lbase + pBr[3]},
+             qE[4] = {lbase + pEr[0], lbase + pEr[1], lbase + pEr[2], lbase + pEr[3]};
+    auto stage_full = [&](int s, int buf_free) {
         double A[2][4], B[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) A[0][i] = src[pA0 + 16 * i];
+        for (int i = 0; i < 4; ++i) A[0][i] = qA[16 * i];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) B[r] = src[pBr[r]];
+        for (int r = 0; r < 4; ++r) B[r] = qB[r][0];
         K4_SB();
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int ks = g >> 2, j = g & 3, ca = ks & 1;
-            const double *pb = src + ((g + 1) >> 2) * 4 * K4_PITCH, *pa = src + (ks + 1) * 4 * K4_PITCH;
+            const int ob = ((g + 1) >> 2) * 4 * K4_PITCH, oa = (ks + 1) * 4 * K4_PITCH;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) K4_MFMA(A[ca][i], B[r], acc[i][j][r]);
                 K4_SB();
                 // rotation r of the next column group takes the place of the one just used
-                if (g < 15) B[r] = pb[pBr[r] + 16 * ((g + 1) & 3)];
-                if (j == 2 && ks < 3) A[ca ^ 1][r] = pa[pA0 + 16 * r];
+                if (g < 15) B[r] = qB[r][ob + 16 * ((g + 1) & 3)];
+                if (j == 2 && ks < 3) A[ca ^ 1][r] = qA[oa + 16 * r];
+                // the six copies of stage s + 2, one at a time behind the barrier (a copy is a handful of scalar
+                // instructions around the load: between MFMAs they cost nothing, in one block they cost 7 us of 135)
+                if (g >= 12 && g <= 14 && (r & 1) && s + 2 < nstages) {
+                    const int idx = 2 * (g - 12) + (r >> 1);      // 0..5: row idx / 3, piece idx % 3
+                    if (idx / 3 < crows) copy_piece(s + 2, buf_free, crow0 + idx / 3, idx % 3);
+                }
+                K4_SB();
+            }
+            if (g == 11) {
+                stage_sync();
+                if (crows > 2 && s + 2 < nstages) copy_rows(s + 2, buf_free, 2);      // more than the six slots below hold
                 K4_SB();
             }
         }
     };
-    auto stage_diag = [&](const double *src) {
-        double A[2][4], R[4][4], E[4];      // R[j][r]: column group a0 + j rotated by 4 r (r = 0 is A[j] itself)
+    // DIAG tasks have 60 MFMAs per four rows against the 64 of a FULL one: they read their first operands at the
+    // start of each stage (complete since the barrier of the stage before) and can afford that latency; carrying
+    // their 24 operand registers across the stages as well spills
+    auto stage_diag = [&](int s, int buf_free) {
+        // R[j][r]: column group a0 + j rotated by 4 r (r = 0 is A[j] itself).  With the edge group (MODE 2) the A
+        // registers are read again in place during the edge blocks, their last use in the four rows; without it
+        // they alternate between two sets.
+        constexpr int NA = MODE == 2 ? 1 : 2;
+        double A[NA][4], R[4][4], E[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) A[0][i] = src[pA0 + 16 * i];
+        for (int i = 0; i < 4; ++i) A[0][i] = qA[16 * i];
 #pragma unroll
         for (int j = 3; j >= 0; --j)
 #pragma unroll
-            for (int r = 1; r < 4; ++r) R[j][r] = src[pBr[r] + 16 * j];
-        if (MODE == 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) E[r] = src[pEr[r]];
-        }
+            for (int r = 1; r < 4; ++r) R[j][r] = qB[r][16 * j];
         K4_SB();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int ca = ks & 1;
-            const double *p1 = src + (ks + 1) * 4 * K4_PITCH;
+            const int ca = MODE == 2 ? 0 : ks & 1;
+            const int o0 = ks * 4 * K4_PITCH, o1 = o0 + 4 * K4_PITCH;
             // column groups 3, 2, 1, 0: blocks (i, j), i <= j
 #pragma unroll
             for (int j = 3; j >= 0; --j) {
@@ -880,43 +921,59 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
 #pragma unroll
                     for (int i = 0; i <= j; ++i) K4_MFMA(A[ca][i], r == 0 ? A[ca][j] : R[j][r], acc[i][j][r]);
                     K4_SB();
-                    if (ks < 3 && r > 0) R[j][r] = p1[pBr[r] + 16 * j];
-                    if (ks < 3 && j == 1) A[ca ^ 1][r] = p1[pA0 + 16 * r];
+                    if (ks < 3 && r > 0) R[j][r] = qB[r][o1 + 16 * j];
+                    if (MODE != 2 && ks < 3 && j == 1) A[ca ^ 1][r] = qA[o1 + 16 * r];
+                    if (MODE == 2 && j == 1) E[r] = qE[r][o0];
                     K4_SB();
                 }
             }
             if (MODE == 2) {
                 // free slots (1,0) (2,0) (2,1) (3,0): blocks (a0 + 0..3, edge); (3,1): the corner block
+                if (has_corner) {
 #pragma unroll
-                for (int r = 3; r >= 0; --r) {
-                    K4_MFMA(A[ca][0], E[r], acc[1][0][r]);
-                    K4_MFMA(A[ca][1], E[r], acc[2][0][r]);
-                    K4_MFMA(A[ca][2], E[r], acc[2][1][r]);
-                    K4_MFMA(A[ca][3], E[r], acc[3][0][r]);
-                    if (has_corner) K4_MFMA(E[0], E[r], acc[3][1][r]);
+                    for (int r = 0; r < 4; ++r) K4_MFMA(E[0], E[r], acc[3][1][r]);
+                }
+                K4_SB();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) K4_MFMA(A[0][i], E[r], acc[i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 2 : 3][i == 2 ? 1 : 0][r]);
                     K4_SB();
-                    if (ks < 3) E[r] = p1[pEr[r]];
+                    if (ks < 3) A[0][i] = qA[o1 + 16 * i];
                     K4_SB();
                 }
             }
+            if (ks == 2) {
+                stage_sync();       // (a DIAG wave copies no rows: k4_build_tasks)
+                K4_SB();
+            }
         }
     };
-    // two stage buffers: the copy of stage s + 1 runs while stage s is multiplied.  (A third buffer with the copy two
-    // stages ahead and a counted vmcnt measured the same, 136.0 against 135.3 us: the copies are not late.)
-    if (nstages > 0) fetch(0, 0);
+    if (nstages > 0) copy_rows(0, 0, 0);
+    if (nstages > 1) copy_rows(1, 1, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int buf = 0;
     for (int s = 0; s < nstages; ++s) {
-        if (s + 1 < nstages) fetch(s + 1, (s + 1) & 1);
-        const double *src = lds + (size_t)(s & 1) * K4_KB * K4_PITCH;
+        const int buf_next = buf == 2 ? 0 : buf + 1, buf_free = buf == 0 ? 2 : buf - 1;
         if (!GEN) {
-            if (DIAG) stage_diag(src); else stage_full(src);
-        } else if (nA > 0) {
+            if (DIAG) stage_diag(s, buf_free); else stage_full(s, buf_free);
+            const int d = (buf_next - buf) * K4_KB * K4_PITCH;
+            qA += d;
 #pragma unroll
-            for (int ks = 0; ks < K4_KB; ks += 4) kstep(src + ks * K4_PITCH);
+            for (int r = 0; r < 4; ++r) { qB[r] += d; qE[r] += d; }
+        } else {
+            const double *src = stage_buf(buf);
+            if (nA > 0) {
+#pragma unroll
+                for (int ks = 0; ks < K4_KB - 4; ks += 4) kstep(src + ks * K4_PITCH);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_sync();
+            if (s + 2 < nstages) copy_rows(s + 2, buf_free, 0);
+            if (nA > 0) kstep(src + (K4_KB - 4) * K4_PITCH);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of stage s + 1 have landed
-        __syncthreads();
+        buf = buf_next;
     }
 #undef K4_SB
     if (nA <= 0) return;
@@ -954,7 +1011,7 @@ __global__ void __launch_bounds__(64 * K4_WAVES, 2) k_schur_syrk4(K4Args a) {
     t.a0 = __builtin_amdgcn_readfirstlane(t.a0); t.b0 = __builtin_amdgcn_readfirstlane(t.b0);
     t.nA = __builtin_amdgcn_readfirstlane(t.nA); t.nB = __builtin_amdgcn_readfirstlane(t.nB);
     t.diag = __builtin_amdgcn_readfirstlane(t.diag); t.edge = __builtin_amdgcn_readfirstlane(t.edge);
-    t.corner = __builtin_amdgcn_readfirstlane(t.corner);
+    t.corner = __builtin_amdgcn_readfirstlane(t.corner); t.copy = __builtin_amdgcn_readfirstlane(t.copy);
     const bool whole = t.nA == 4 && t.nB == 4;
     // The waves of a workgroup run different k4_body instantiations and still meet at the same barriers: s_barrier
     // counts arrivals, not program counters.  The invariant every instantiation keeps is the NUMBER of barriers a
@@ -985,6 +1042,26 @@ inline int k4_build_tasks(int nb, std::vector<K4Task> &tasks) {
     }
     const int parts = ((int)tasks.size() + K4_WAVES - 1) / K4_WAVES;
     while ((int)tasks.size() < parts * K4_WAVES) tasks.push_back(K4Task{0, 0, 0, 0, 0, -1, 0, 0});
+    // who copies the K4_KB rows of a stage into LDS: the idle waves of the workgroup if it has any (they have nothing
+    // else to do), else its FULL waves (a copy fits between their MFMAs); never a DIAG wave, which has no registers
+    // to spare for it (at most six DIAG tasks exist, so every workgroup has another kind of wave); consecutive rows,
+    // shared evenly
+    for (int p = 0; p < parts; ++p) {
+        K4Task *w = tasks.data() + (size_t)p * K4_WAVES;
+        int n_idle = 0, n_full = 0;
+        for (int i = 0; i < K4_WAVES; ++i) { n_idle += w[i].nA == 0; n_full += w[i].nA > 0 && !w[i].diag; }
+        if (n_idle + n_full == 0) { tasks.clear(); return 0; }       // (cannot happen for ZC <= K4_PITCH)
+        const int nf = n_idle ? n_idle : n_full;
+        int row = 0, f = 0;
+        for (int i = 0; i < K4_WAVES; ++i) {
+            const bool mine = n_idle ? w[i].nA == 0 : (w[i].nA > 0 && !w[i].diag);
+            w[i].copy = 0;
+            if (!mine) continue;
+            const int cnt = (K4_KB - row + (nf - f) - 1) / (nf - f);
+            w[i].copy = row | cnt << 8;
+            row += cnt; ++f;
+        }
+    }
     return parts;
 }
 
