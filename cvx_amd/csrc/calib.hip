@@ -13,6 +13,7 @@
 #include "common.h"
 #include "lm_driver.h"
 #include "solve_kernels.h"
+#include "step_kernels.h"
 
 using namespace cvxk;
 
@@ -428,15 +429,16 @@ private:
                                    h->npad, ns, k, h->nT, h->d_fail, h->d_delta_s);
             CVX_HIP(hipGetLastError());
         }
-        {
-            cvxs::FinishArgs f;
-            f.n = ns;
-            f.E = h->d_E; f.E_scal = (long long)h->E_scal; f.nranks = h->nranks; f.Ds = h->d_Ds; f.fail = h->d_fail;
-            f.C = h->C; f.P = h->P; f.ncf = h->ncf; f.fix_k3 = h->fix_k3; f.cam_free = h->cam_free; f.pts_free = h->pts_free;
-            f.ZC = h->ZC; f.camcol0 = h->camcol0; f.ycol = h->ycol;
-            f.intr = h->d_intr[h->cur]; f.points = h->d_points[h->cur];
-            f.intr_cand = h->d_intr[nxt]; f.points_cand = h->d_points[nxt];
-            f.ds_emb = h->d_ds_emb; f.delta_s = h->d_delta_s; f.R = h->d_E2;
+        cvxs::FinishArgs f;
+        f.n = ns;
+        f.E = h->d_E; f.E_scal = (long long)h->E_scal; f.nranks = h->nranks; f.Ds = h->d_Ds; f.fail = h->d_fail;
+        f.C = h->C; f.P = h->P; f.ncf = h->ncf; f.fix_k3 = h->fix_k3; f.cam_free = h->cam_free; f.pts_free = h->pts_free;
+        f.ZC = h->ZC; f.camcol0 = h->camcol0; f.ycol = h->ycol;
+        f.intr = h->d_intr[h->cur]; f.points = h->d_points[h->cur];
+        f.intr_cand = h->d_intr[nxt]; f.points_cand = h->d_points[nxt];
+        f.ds_emb = h->d_ds_emb; f.delta_s = h->d_delta_s; f.R = h->d_E2;
+        if (h->V == 0) {
+            // no pose blocks: the step's bookkeeping is a kernel of its own
             if (h->fin_lds > 64 * 1024)
                 CVX_HIP(hipFuncSetAttribute((const void *)cvxs::k_step_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fin_lds));
             hipLaunchKernelGGL(cvxs::k_step_finish, dim3(1), dim3(cvxs::FIN_THREADS), h->fin_lds, h->stream, f);
@@ -445,12 +447,15 @@ private:
         ph_end(h, PH_SOLVE);
         ph_begin(h, PH_BACKSUBST);
         if (h->V > 0) {
-            // pose steps, candidate poses and the candidate's cost per view in one pass
-            hipLaunchKernelGGL(k_backsubst_cost, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, h->d_Z, h->d_Linv, h->d_Dv,
-                               h->d_gv, h->d_ds_emb, h->d_cam_of_view, h->d_poses[h->cur], h->d_poses[nxt],
-                               keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V, h->ZC,
-                               h->d_view_off, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[nxt], h->d_points[nxt],
-                               h->d_cost_view);
+            // pose steps, candidate poses and the candidate's cost per view in one pass; workgroup 0 also makes the
+            // candidate's shared parameters and the scalars of the step (step_kernels.h)
+            const size_t bsc_lds = h->fin_lds + sizeof(double) * 3 * (size_t)h->P;      // finish area | candidate points
+            if (bsc_lds > 64 * 1024)
+                CVX_HIP(hipFuncSetAttribute((const void *)k_backsubst_cost_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsc_lds));
+            hipLaunchKernelGGL(k_backsubst_cost_step, dim3((h->V + 3) / 4), dim3(BSC_THREADS), bsc_lds, h->stream, h->d_Z,
+                               h->d_Linv, h->d_Dv, h->d_gv, h->d_cam_of_view, h->d_poses[h->cur], h->d_poses[nxt],
+                               keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V,
+                               h->d_view_off, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_cost_view, f);
             CVX_HIP(hipGetLastError());
         }
         ph_end(h, PH_BACKSUBST);
