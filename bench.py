@@ -446,8 +446,8 @@ def main():
             except Exception:
                 traffic = None
         roof = {"kernel": {"schur": "k_schur_syrk4", "normal_eq": "k_normal_eq", "assemble": "k_reduce_all+k_assemble",
-                           "backsubst": "k_backsubst_cost", "cost": "k_final_scalars",
-                           "solve": "k_damp_prepare+k_chol_step+k_solve_finish"}[dom],
+                           "backsubst": "k_backsubst_cost_step", "cost": "k_final_scalars",
+                           "solve": "k_chol_step"}[dom],
                 "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                 "frac": achieved / peak, "traffic": traffic,
                 "avg_launch_ms": per_launch[dom], "algorithmic_per_launch": amount,

@@ -1329,164 +1329,6 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------
-// K6: back-substitution, one wave per view:
-//   t = Z_v * ds_emb[cam]  (ds_emb has 1 in the y column)   ->  dp = -L_v^-T t
-//   candidate pose = pose + dp;  per-view sums for the step evaluation
-// out_view[k][v] (three planes) = dp^T (D dp - g), |dp|^2, |pose|^2
-// -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_backsubst(const double *__restrict__ Z, const double *__restrict__ Lfac,
-                                                   const double *__restrict__ Dv, const double *__restrict__ gv,
-                                                   const double *__restrict__ ds_emb,
-                                                   const int *__restrict__ cam_of_view,
-                                                   const double *__restrict__ poses, double *__restrict__ poses_cand,
-                                                   double *__restrict__ dposes, double *__restrict__ out_view, int V,
-                                                   int ZC) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= V) return;
-    const double *ds = ds_emb + (size_t)cam_of_view[v] * ZC;
-    const double *Zv = Z + (size_t)6 * v * ZC;
-    double t[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = 2 * lane; c < ZC; c += 128) {       // ZC is a multiple of 16: 16-byte loads, 1 KB per wave instruction
-        const double2 d = *(const double2 *)(ds + c);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double2 z = *(const double2 *)(Zv + (size_t)i * ZC + c);
-            t[i] += z.x * d.x + z.y * d.y;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t[i] += __shfl_xor(t[i], off, 64);
-    if (lane == 0) {
-        const double *Lf = Lfac + (size_t)21 * v;     // off-diagonal L, diagonal slots 1 / L_ii
-        double x[6];
-#pragma unroll
-        for (int i = 5; i >= 0; --i) {
-            double s = t[i];
-#pragma unroll
-            for (int k = i + 1; k < 6; ++k) s -= Lf[TRI(k, i)] * x[k];
-            x[i] = s * Lf[TRI(i, i)];
-        }
-        double m = 0.0, s2 = 0.0, x2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double dp = -x[i];
-            const double p = poses[6 * v + i];
-            poses_cand[6 * v + i] = p + dp;
-            if (dposes) dposes[6 * v + i] = dp;
-            m += dp * (Dv[6 * v + i] * dp - gv[6 * v + i]);
-            s2 += dp * dp;
-            x2 += p * p;
-        }
-        out_view[v] = m;
-        out_view[V + v] = s2;
-        out_view[2 * (size_t)V + v] = x2;
-    }
-}
-
-// -----------------------------------------------------------------------------------------
-// K6 + K4 fused, one wave per view: the back-substitution above, then the candidate's cost over the view's own
-// observations with the candidate rotation held in registers (same expressions as k_pose_prepare, so the value
-// equals what k_cost computes from the tables).  cost_view[v] = sum r^2 of the view at the candidate point.
-// -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_backsubst_cost(const double *__restrict__ Z, const double *__restrict__ Lfac,
-                                                        const double *__restrict__ Dv, const double *__restrict__ gv,
-                                                        const double *__restrict__ ds_emb,
-                                                        const int *__restrict__ cam_of_view,
-                                                        const double *__restrict__ poses, double *__restrict__ poses_cand,
-                                                        double *__restrict__ dposes, double *__restrict__ out_view, int V,
-                                                        int ZC, const int *__restrict__ view_off,
-                                                        const int *__restrict__ point_id, const double *__restrict__ obs_x,
-                                                        const double *__restrict__ obs_y, const double *__restrict__ intr_cand,
-                                                        const double *__restrict__ points_cand,
-                                                        double *__restrict__ cost_view) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= V) return;
-    const int cam = cam_of_view[v];
-    const double *ds = ds_emb + (size_t)cam * ZC;
-    const double *Zv = Z + (size_t)6 * v * ZC;
-    // the view's observations do not depend on the step: fetch them first
-    const int o0 = view_off[v], o1 = view_off[v + 1];
-    double t[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = 2 * lane; c < ZC; c += 128) {       // ZC is a multiple of 16: 16-byte loads, 1 KB per wave instruction
-        const double2 d = *(const double2 *)(ds + c);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double2 z = *(const double2 *)(Zv + (size_t)i * ZC + c);
-            t[i] += z.x * d.x + z.y * d.y;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t[i] += __shfl_xor(t[i], off, 64);
-    // every lane carries the (wave-uniform) substitution: the candidate pose is needed by all of them
-    const double *Lf = Lfac + (size_t)21 * v;         // off-diagonal L, diagonal slots 1 / L_ii
-    double x[6], pc[6];
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double s = t[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; ++k) s -= Lf[TRI(k, i)] * x[k];
-        x[i] = s * Lf[TRI(i, i)];
-    }
-    double m = 0.0, s2 = 0.0, x2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double dp = -x[i];
-        const double p = poses[6 * v + i];
-        pc[i] = p + dp;
-        m += dp * (Dv[6 * v + i] * dp - gv[6 * v + i]);
-        s2 += dp * dp;
-        x2 += p * p;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            poses_cand[6 * v + i] = pc[i];
-            if (dposes) dposes[6 * v + i] = -x[i];
-        }
-        out_view[v] = m;
-        out_view[V + v] = s2;
-        out_view[2 * (size_t)V + v] = x2;
-    }
-    // rotation of the candidate pose: the R part of k_pose_prepare, in registers
-    double rtl[RT_STRIDE];
-    {
-        const double w0 = pc[0], w1 = pc[1], w2 = pc[2];
-        const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
-        if (th2 > 2.220446049250313e-16) {
-            const double th = sqrt(th2), c = cos(th), s = sin(th), ti = 1.0 / th, omc = 1.0 - c;
-            const double a[3] = {w0 * ti, w1 * ti, w2 * ti};
-            const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) rtl[i * 3 + k] = (i == k ? c : 0.0) + s * K[i * 3 + k] + omc * a[i] * a[k];
-        } else {
-            const double Rs[9] = {1, -w2, w1, w2, 1, -w0, -w1, w0, 1};
-#pragma unroll
-            for (int i = 0; i < 9; ++i) rtl[i] = Rs[i];
-        }
-        rtl[36] = pc[3]; rtl[37] = pc[4]; rtl[38] = pc[5];
-    }
-    const Intr in = load_intr(intr_cand + 9 * cam);
-    double acc = 0.0;
-    for (int o = o0 + lane; o < o1; o += 64) {
-        const double *X = points_cand + 3 * point_id[o];
-        double r0, r1;
-        reproj_residual(in, rtl, X[0], X[1], X[2], obs_x[o], obs_y[o], r0, r1);
-        acc += r0 * r0 + r1 * r1;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) cost_view[v] = acc;
-}
-
-// -----------------------------------------------------------------------------------------
 // final scalar reduction (single block of 1024, fixed order):
 //   E2 = { sum cost partials, sum out_view[0][.], sum out_view[1][.], sum out_view[2][.] }
 // each thread sums a strided slice of each array
@@ -1529,7 +1371,7 @@ __global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict
                 (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
             E2[threadIdx.x] = v;
         } else {
-            v = E2[threadIdx.x];              // the step's scalars, left there by k_solve_finish
+            v = E2[threadIdx.x];              // the step's scalars, left there by workgroup 0 of k_backsubst_cost_step (or k_step_finish)
         }
         // single-rank runs: the 16 doubles go straight into host-mapped memory, then a sequence number the host
         // polls for (no copy kernel, no interrupt); the first wave holds all 16 writers, so no block barrier

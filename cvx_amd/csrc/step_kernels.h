@@ -1,11 +1,14 @@
-// The last big kernel of an LM linear step with the step's bookkeeping folded in: k_backsubst_cost (calib_kernels.h)
-// that needs no k_step_finish (solve_kernels.h) in front of it.  What k_step_finish made for it -- the step laid out
-// in Z's column order per camera (ds_emb), the candidate intrinsics and points -- is a handful of adds on the solution
-// x of the reduced system, so every wave makes what it needs from x itself (same single additions: same values), and
-// workgroup 0 does the rest of k_step_finish's work on the side: the candidate arrays the NEXT kernels read, and the
-// scalars of the step.  One launch and 6 us less per iteration.  Follows the same reference lines as the two kernels
-// it merges (/root/reference/modules/calib/src/calibration.cpp:420-433: after the linear solve the candidate point
-// x + delta is evaluated and compared with the model's prediction).
+// K6 + K4 of an LM linear step, one wave per view, with the step's bookkeeping folded in.
+//   K6  t = Z_v * ds_emb[cam]  (the step embedded in Z's column order, 1 in the gradient column)  ->  dp = -L_v^-T t;
+//       candidate pose = pose + dp;  out_view[k][v] (three planes) = dp^T (D dp - g), |dp|^2, |pose|^2
+//   K4  the candidate's cost over the view's own observations, with the candidate rotation held in registers (same
+//       expressions as k_pose_prepare, so the value equals what k_cost computes from the tables): cost_view[v]
+// What a one-workgroup k_step_finish (solve_kernels.h) used to make in front of this kernel -- ds_emb, the candidate
+// intrinsics and points -- is a handful of adds on the solution x of the reduced system, so every wave makes what it
+// needs from x itself (same single additions: same values), and workgroup 0 does the rest of k_step_finish's work on
+// the side: the candidate arrays the NEXT kernels read, and the scalars of the step.  One launch and 6 us less per
+// iteration.  Reference: /root/reference/modules/calib/src/calibration.cpp:420-433 (after the linear solve the
+// candidate point x + delta is evaluated and compared with the model's prediction).
 // Included only by calib.hip, after calib_kernels.h and solve_kernels.h.
 #pragma once
 #include "calib_kernels.h"
