@@ -770,16 +770,14 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
 
     // staging: K4_KB rows of ZC doubles per stage, copied global -> LDS by the load unit itself (global_load_lds,
     // 16 bytes per lane: no staging registers, no ds_write pass).  One wave instruction fills 1 KB of LDS, lane l at
-    // base + 16 l, so a row goes in pieces of 1 KB and wave w copies rows 2 w and 2 w + 1.  The pieces are whole:
+    // base + 16 l, so a row goes in pieces of 1 KB; which waves copy which rows is in the task list (k4_build_tasks).  The pieces are whole:
     // the last one of a row runs into the next row of Z (memory that exists: Z ends in eight rows of padding) and
     // lands in the pad columns of the LDS row, which no counted block reads.  Rows past the end of the chunk (last
     // stage only) are copied from Z's padding rows, which are zero.  The copies are issued from inline asm: told of
     // an LDS-DMA in flight, the compiler turns every wait for an LDS operand into lgkmcnt(0), which would stall the
     // operand pipeline below on its newest read; the wait for the copies (vmcnt) is written out before the barrier.
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nstages = (r1 - r0 + K4_KB - 1) / K4_KB;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
-    // copy number idx (0..5) of a stage: row 2 wv + idx / 3 of it, piece idx % 3 (and, ZC > 384, the 128-byte rest)
     const unsigned lane16 = 16u * (unsigned)lane;
     const int crow0 = t.copy & 255, crows = t.copy >> 8;      // this wave's rows of a stage (wave-uniform)
     // piece k (0..2; with k = 2 goes, for ZC > 384, the 128-byte rest) of stage row `row`
@@ -922,7 +920,7 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
                     for (int i = 0; i <= j; ++i) K4_MFMA(A[ca][i], r == 0 ? A[ca][j] : R[j][r], acc[i][j][r]);
                     K4_SB();
                     if (ks < 3 && r > 0) R[j][r] = qB[r][o1 + 16 * j];
-                    if (MODE != 2 && ks < 3 && j == 1) A[ca ^ 1][r] = qA[o1 + 16 * r];
+                    if (MODE != 2 && ks < 3 && j == 1) A[(ca ^ 1) % NA][r] = qA[o1 + 16 * r];
                     if (MODE == 2 && j == 1) E[r] = qE[r][o0];
                     K4_SB();
                 }
