@@ -185,3 +185,19 @@ def test_lm_driver_hands_back_the_lowest_cost_point():
     assert (r["final_cost"], r["at"], r["saved"], r["restored"], r["successful"]) == (40.0, 1, 0, 0, 2)
     b = rows["uphill_then_better"]   # a later, lower minimum makes the saved copy stale: not restored
     assert (b["final_cost"], b["at"], b["restored"]) == (30.0, 3, 0)
+
+
+def test_schur_task_list_covers_every_block_and_every_stage_row_once():
+    """k4_build_tasks (calib_kernels.h): for every width k_schur_syrk4 takes, each 16x16 block of the upper triangle
+    belongs to exactly one task, and in every workgroup the sixteen rows of a stage are copied into LDS exactly once,
+    never by a DIAG wave (which has no registers to spare for it).  Host only: tests/cpp/k4_tasks_test.cpp."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "k4_tasks_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() (make -C cvx_amd/csrc)"
+    p = subprocess.run([exe], capture_output=True, timeout=60)
+    rows = [json.loads(line) for line in p.stdout.decode().splitlines()]
+    assert p.returncode == 0, rows
+    assert [r["nb"] for r in rows] == list(range(1, 26))
+    assert all(r["blocks_wrong"] == 0 and r["copy_wrong"] == 0 and r["diag_copies"] == 0 for r in rows)
+    assert {r["nb"]: r["parts"] for r in rows}[21] == 2      # config 4: 15 tasks on 2 x 8 waves
