@@ -11,7 +11,7 @@ import os
 import sys
 
 PHASE = {"k_schur_syrk": "schur", "k_normal_eq<128, 0, true>": "normal_eq", "k_normal_eq": "normal_eq",
-         "k_backsubst": "backsubst", "k_cost": "cost", "k_eval": "eval", "k_reduce_all": "assemble",
+         "k_backsubst_cost_step": "backsubst", "k_backsubst": "backsubst", "k_cost": "cost", "k_eval": "eval", "k_reduce_all": "assemble",
          "k_chol_step": "solve"}
 
 
