@@ -506,7 +506,11 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
             if (!ok) nbad = 1.0;
             K2_STAMP(4);
             double *Zv = a.Z + (size_t)6 * v * a.ZC;
-            // point columns: Z[.][3 pid + b] = L^-1 (Jp^T Jx)[.][b]
+            // point columns: Z[.][b P + pid] = L^-1 (Jp^T Jx)[.][b].  Z's point columns are coordinate-major (all x, then
+            // all y, then all z): lanes hold consecutive points in the usual board order, so each of these stores is
+            // one contiguous run of 8 bytes per lane; point-major (3 pid + b) they were 8-byte pieces 24 bytes apart,
+            // three instructions to a line, and the kernel is partly bound by the rate at which such pieces are taken
+            // (DESIGN.md section 4).  The column order is private to Z: k_assemble and the step's embedding map it.
             if (active && a.pts_free) {
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
@@ -515,7 +519,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
                     for (int k = 0; k < 6; ++k) w[k] = fma(Jp[6 + k], Jx[3 + b], Jp[k] * Jx[b]);
                     chol6_forward(A, w);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + 3 * pid + b] = w[i];
+                    for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + b * a.P + pid] = w[i];
                 }
             }
             K2_STAMP(6);
@@ -1225,7 +1229,7 @@ __device__ __forceinline__ SharedIdx shared_index(const AsmArgs &a, int i) {
         s.p = 0; s.b = 0; s.zcol = a.camcol0 + s.kk;
     } else {
         const int q = i - ncam;
-        s.is_cam = 0; s.c = -1; s.kk = 0; s.p = q / 3; s.b = q % 3; s.zcol = q;
+        s.is_cam = 0; s.c = -1; s.kk = 0; s.p = q / 3; s.b = q % 3; s.zcol = s.b * a.P + s.p;
     }
     return s;
 }

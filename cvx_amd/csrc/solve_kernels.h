@@ -356,7 +356,8 @@ __device__ __forceinline__ void finish_tail(const FinishArgs &a, const double *x
     for (int e = tid; e < a.C * a.ZC; e += NT) {
         const int c = e / a.ZC, col = e % a.ZC;
         double v = 0.0;
-        if (a.pts_free && col < 3 * a.P) v = xs[ncam + col];
+        const int cb = (col >= a.P) + (col >= 2 * a.P);      // Z's point columns are coordinate-major: column b P + p is unknown 3 p + b
+        if (a.pts_free && col < 3 * a.P) v = xs[ncam + 3 * (col - cb * a.P) + cb];
         else if (a.cam_free && col >= a.camcol0 && col < a.camcol0 + 9) {
             const int kk = col - a.camcol0;
             if (!(a.fix_k3 && kk == 6)) v = xs[c * a.ncf + ((a.fix_k3 && kk > 6) ? kk - 1 : kk)];

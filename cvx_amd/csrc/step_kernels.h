@@ -23,7 +23,8 @@ __device__ __forceinline__ double step_emb(const cvxs::FinishArgs &a, const doub
     const int kk = col - a.camcol0;
     const bool is_cam = !is_pt && a.cam_free && kk >= 0 && kk < 9;
     const bool use_cam = is_cam && !(a.fix_k3 && kk == 6);
-    const int idx = is_pt ? a.C * a.ncf + col : use_cam ? cam * a.ncf + ((a.fix_k3 && kk > 6) ? kk - 1 : kk) : 0;
+    const int cb = (col >= a.P) + (col >= 2 * a.P);      // Z's point columns are coordinate-major: column b P + p is unknown 3 p + b
+    const int idx = is_pt ? a.C * a.ncf + 3 * (col - cb * a.P) + cb : use_cam ? cam * a.ncf + ((a.fix_k3 && kk > 6) ? kk - 1 : kk) : 0;
     const double v = x[idx];      // x holds at least one element
     return (is_pt || use_cam) ? v : (!is_cam && col == a.ycol) ? 1.0 : 0.0;
 }
