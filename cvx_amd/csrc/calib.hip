@@ -930,7 +930,7 @@ extern "C" int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]) {
     return CVX_OK;
 }
 
-#ifdef K2_PROF
+#if defined(K2_PROF) || defined(K2_WALL)
 extern "C" int cvx_calib_debug_group_scalars(cvx_calib *h, double *out) {
     CVX_HIP(hipMemcpy(out, h->d_grp_scal, sizeof(double) * 4 * h->n_groups, hipMemcpyDeviceToHost));
     return h->n_groups;

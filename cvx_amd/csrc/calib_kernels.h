@@ -359,6 +359,10 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
     extern __shared__ double lds[];
     constexpr int W = T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef K2_WALL
+    const long long w_start = wall_clock64();
+    long long w_pro = 0, w_loop = 0;
+#endif
     // ALIGNED: every view of the group lists the same points in the same order, so thread tid meets the
     // same point in every view and its U_cx | U_xx | g_x accumulators stay in registers; otherwise they
     // live in LDS, indexed by point id
@@ -392,6 +396,9 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 #define K2_STAMP(i) do { const long long tn = clock64(); ph[i] += tn - tp; tp = tn; } while (0)
 #else
 #define K2_STAMP(i) do {} while (0)
+#endif
+#ifdef K2_WALL
+    w_pro = wall_clock64();
 #endif
     for (int v = v0; v < v1; ++v) {
 #ifdef K2_PROF
@@ -550,6 +557,9 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
         }
         K2_STAMP(5);
     }
+#ifdef K2_WALL
+    w_loop = wall_clock64();
+#endif
     // ---- flush the group's accumulators ----
     double *sp = a.slab_pt + (size_t)g * a.P * PT_ACC;
     if (a.pts_free) {
@@ -576,7 +586,10 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
         a.grp_scal[4 * g + 0] = gmax;
         a.grp_scal[4 * g + 1] = dmax;
         a.grp_scal[4 * g + 2] = nbad;
-#ifdef K2_PROF
+#ifdef K2_WALL
+        { const long long w_end = wall_clock64();
+          a.grp_scal[4 * g + 3] = (g % 4 == 0) ? (double)w_start : (g % 4 == 1) ? (double)w_pro : (g % 4 == 2) ? (double)w_loop : (double)w_end; }
+#elif defined(K2_PROF)
         a.grp_scal[4 * g + 3] = (double)ph[g % 8];
 #else
         a.grp_scal[4 * g + 3] = 0.0;
