@@ -610,6 +610,16 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 // blockIdx -> (chunk, part): the parts of one chunk sit on one XCD (blockIdx % 8), which keeps the
 // second read of the chunk's rows in that XCD's L2.
 // -----------------------------------------------------------------------------------------
+// Where entry (row, col) of a 16x16 partial block lies among the block's 256 doubles in the slab (and in the per-camera
+// sums made from it): in the order in which k_schur_syrk4's lanes hold it, so that its result leaves the registers as
+// two 16-byte stores per lane and block, 1 KB contiguous per instruction (row-major it was four 8-byte stores, 32-byte
+// pieces of 16 different lines each).  Lane l = 16 i + 4 b + j of accumulator r holds row 4 b + i, column
+// 4 ((b - r) & 3) + j; it stores accumulators 0, 1 at doubles 2 l, 2 l + 1 and accumulators 2, 3 at 128 + 2 l, + 1.
+__host__ __device__ inline int k4_slot(int row, int col) {
+    const int b = row >> 2, i = row & 3, r = (b - (col >> 2)) & 3, l = 16 * i + 4 * b + (col & 3);
+    return 128 * (r >> 1) + 2 * l + (r & 1);
+}
+
 constexpr int K3_WAVES = 12, K3_MAXB = 10, K3_CAP = K3_WAVES * K3_MAXB;
 
 struct K3Args {
@@ -693,7 +703,7 @@ __global__ void __launch_bounds__(64 * K3_WAVES) k_schur_syrk(K3Args a) {
         if (i < cnt) {
             double *out = a.slab + ((size_t)chunk * a.nblk + q0 + i) * 256;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out[(kq + 4 * q) * 16 + cq] = acc[i][q];
+            for (int q = 0; q < 4; ++q) out[k4_slot(kq + 4 * q, cq)] = acc[i][q];
         }
 }
 
@@ -993,13 +1003,12 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
 #undef K4_SB
     if (nA <= 0) return;
     // accumulator r of block (gA, gB), lane l: row 4b + i, column 4((b - r) & 3) + j with i = l >> 4, b = (l >> 2) & 3,
-    // j = l & 3 (the rotation by 4r hands block b the B block b - r)
-    const int li = lane >> 4, lb = (lane >> 2) & 3, lj = lane & 3;
+    // j = l & 3 (the rotation by 4r hands block b the B block b - r); the slab keeps that order (k4_slot)
     auto put = [&](int gA, int gB, const double (&v)[4]) {
         const int q = gA * nb - gA * (gA - 1) / 2 + (gB - gA);
-        double *out = a.slab + ((size_t)chunk * a.nblk + q) * 256 + (4 * lb + li) * 16 + lj;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[4 * ((lb - r) & 3)] = v[r];
+        double *out = a.slab + ((size_t)chunk * a.nblk + q) * 256 + 2 * lane;      // k4_slot order
+        *(double2 *)(out) = double2{v[0], v[1]};
+        *(double2 *)(out + 128) = double2{v[2], v[3]};
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1253,7 +1262,7 @@ __device__ __forceinline__ size_t tile_offset(const AsmArgs &a, int zi, int zj) 
     int bi = zi >> 4, bj = zj >> 4;
     if (bi > bj) { int t = bi; bi = bj; bj = t; t = zi; zi = zj; zj = t; }
     const int q = bi * a.nb - bi * (bi - 1) / 2 + (bj - bi);
-    return (size_t)q * 256 + (zi & 15) * 16 + (zj & 15);
+    return (size_t)q * 256 + k4_slot(zi & 15, zj & 15);
 }
 
 // sum of the cameras' tile entries: all cameras (cam < 0) or one
