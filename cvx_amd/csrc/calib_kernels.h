@@ -1024,9 +1024,17 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
     }
 }
 
+#ifdef K4_WALL
+__device__ long long g_k4wall[2 * 4096];      // development: start / end of every workgroup (100 MHz)
+#endif
+
 __global__ void __launch_bounds__(64 * K4_WAVES, 2) k_schur_syrk4(K4Args a) {
     extern __shared__ double lds[];      // [K4_BUFS][K4_KB][K4_PITCH]
     const int b = blockIdx.x;
+#ifdef K4_WALL
+    if (threadIdx.x == 0) g_k4wall[2 * b] = wall_clock64();
+    struct Stamp { int b; __device__ ~Stamp() { if (threadIdx.x == 0) g_k4wall[2 * b + 1] = wall_clock64(); } } stamp{b};
+#endif
     const int xcd = b & 7, slot = b >> 3;
     const int part = slot % a.parts, chunk = (slot / a.parts) * 8 + xcd;
     if (chunk >= a.n_chunks) return;

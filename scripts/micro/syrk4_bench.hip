@@ -52,6 +52,15 @@ int main(int argc, char **argv) {
     const double flop = 2.0 * rows * 256.0 * nblk;
     printf("16x16x4: %.1f us  %.1f TFLOP/s executed    4x4x4: %.1f us  %.1f TFLOP/s executed\n", 1e3 * ms3 / reps, flop / (ms3 / reps) / 1e9,
            1e3 * ms4 / reps, flop / (ms4 / reps) / 1e9);
+#ifdef K4_WALL
+    { std::vector<long long> w(2 * 4096); CK(hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(cvxk::g_k4wall), w.size() * 8));
+      long long t0 = w[0]; for (int b = 0; b < g4; ++b) if (w[2 * b] && w[2 * b] < t0) t0 = w[2 * b];
+      for (int part = 0; part < parts4; ++part) {
+          double s0 = 0, s1 = 0, e1max = 0, e1min = 1e30; int cnt = 0;
+          for (int b = 0; b < g4; ++b) { if (((b >> 3) % parts4) != part || !w[2 * b + 1]) continue;
+              s0 += (w[2 * b] - t0) * 0.01; s1 += (w[2 * b + 1] - t0) * 0.01; e1max = fmax(e1max, (w[2 * b + 1] - t0) * 0.01); e1min = fmin(e1min, (w[2 * b + 1] - t0) * 0.01); ++cnt; }
+          printf("part %d: %d workgroups, wave 0 starts at %.2f us, ends at %.2f us on average (min %.2f, max %.2f)\n", part, cnt, s0 / cnt, s1 / cnt, e1min, e1max); } }
+#endif
     std::vector<double> h3(slab), h4(slab);
     CK(hipMemcpy(h3.data(), s3, slab * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h4.data(), s4, slab * 8, hipMemcpyDeviceToHost));
     double maxd = 0, maxv = 0; size_t bad = 0, firstbad = (size_t)-1;
