@@ -469,6 +469,8 @@ static void lm_defaults(orc_lm_options *o) {
     o->nonmonotonic = 0;
     o->max_consecutive_nonmonotonic_steps = 5;
     o->tau = 1e-3; o->eps1 = o->eps2 = o->eps3 = 1e-17;   /* levmar.h:90-91 */
+    o->inner_iterations = 0;
+    o->inner_iteration_tolerance = 1e-3;
 }
 void orc_lm_options_refine(orc_lm_options *o) {   /* calibration.cpp:420-428 */
     lm_defaults(o);
@@ -502,6 +504,8 @@ typedef struct {
     void (*plus)(void *ctx, const double *x, const double *delta, double *xout);
     double (*cost)(void *ctx, const double *x);
     double (*free_norm2)(void *ctx, const double *x);   /* Nielsen's ||p||^2 */
+    /* inner iterations on a candidate point, in place; returns its new cost (NULL: the model has none) */
+    double (*inner)(void *ctx, double *x);
 } lm_model;
 
 static void trace_push(orc_lm_summary *s, double cost, int acc, double damp, double grad) {
@@ -527,9 +531,15 @@ static double gradient_max_norm(const lm_model *m, const double *x, const double
 
 /* Ceres-style Levenberg-Marquardt trust region (TrustRegionMinimizer +
  * LevenbergMarquardtStrategy + TrustRegionStepEvaluator), restated from the
- * published algorithm; inner iterations are not restated and every linear solve
- * is exact.  With non-monotonic steps the lowest-cost point visited is what the
- * run returns (documented behaviour of use_nonmonotonic_steps). */
+ * published algorithm; every linear solve is exact.  With non-monotonic steps
+ * the lowest-cost point visited is what the run returns (documented behaviour of
+ * use_nonmonotonic_steps).  Inner iterations (options.inner_iterations, models
+ * that have an `inner` callback) as TrustRegionMinimizer::DoInnerIterationsIfNeeded
+ * and IsStepSuccessful use them: the candidate goes through one coordinate-descent
+ * pass, the cost that pass gains is added to the model's predicted change, a
+ * step whose pass ends below the current cost is accepted whatever its ratio,
+ * and the passes stop for good once one gains less than
+ * inner_iteration_tolerance of the candidate's cost. */
 static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_lm_summary *sum) {
     const int nf = m->nfree, ng = m->nglobal;
     double *diag = malloc(sizeof(double) * nf), *grad = malloc(sizeof(double) * nf);
@@ -554,6 +564,7 @@ static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_l
     double ev_acc_ref = 0, ev_acc_cand = 0; int ev_nonmono = 0;
     const int max_nonmono = o->nonmonotonic ? o->max_consecutive_nonmonotonic_steps : 0;
     int term = 0, invalid_run = 0;
+    int inner_enabled = o->inner_iterations && m->inner != NULL;
     if (gmax <= o->gradient_tolerance) term = 1;
 
     int it = 0;
@@ -583,6 +594,15 @@ static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_l
         invalid_run = 0;
         m->plus(m->ctx, x, delta, xc);
         double cand = m->cost(m->ctx, xc);
+        int inner_useful = 0;
+        if (inner_enabled && isfinite(cand)) {
+            const double ic = m->inner(m->ctx, xc);
+            sum->num_inner_iteration_steps++;
+            model_change += cand - ic;
+            inner_useful = ic < cost;
+            inner_enabled = (1.0 - ic / cand) > o->inner_iteration_tolerance;
+            cand = ic;
+        }
         /* step / x norms in the global parameter space */
         double sn = 0; for (int i = 0; i < ng; ++i) { double d = x[i] - xc[i]; sn += d * d; } sn = sqrt(sn);
         double xn = vec_norm(x, ng);
@@ -598,7 +618,7 @@ static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_l
         double rel = (ev_cur - cand) / model_change;
         double hist = (ev_ref - cand) / (ev_acc_ref + model_change);
         double rho = (max_nonmono > 0 && hist > rel) ? hist : rel;
-        if (rho > o->min_relative_decrease) {
+        if (inner_useful || rho > o->min_relative_decrease) {
             trace_push(sum, cand, 1, radius, gmax);
             memcpy(x, xc, sizeof(double) * ng);
             if (cand < best_cost) { best_cost = cand; memcpy(xbest, x, sizeof(double) * ng); }
@@ -1071,6 +1091,192 @@ void orc_calib_reduced_system(const orc_calib_problem *pb, const double *intr, c
     calib_lin_free(&L);
 }
 
+/* ---- inner iterations (coordinate descent over independent sets of parameter blocks) ---- */
+enum { IB_CAM = 0, IB_POINT = 1, IB_POSE = 2 };
+
+typedef struct { long long key; } ib_edge;
+static int ib_cmp_ll(const void *a, const void *b) {
+    long long x = *(const long long *)a, y = *(const long long *)b;
+    return x < y ? -1 : x > y;
+}
+typedef struct { int deg, rank, id; } ib_vert;
+static int ib_cmp_vert(const void *a, const void *b) {
+    const ib_vert *x = a, *y = b;
+    if (x->deg != y->deg) return x->deg < y->deg ? -1 : 1;
+    return x->rank < y->rank ? -1 : x->rank > y->rank;
+}
+
+int orc_calib_inner_ordering(const orc_calib_problem *pb, int *group) {
+    const int C = pb->C, P = pb->P, V = pb->V, NB = C + P + V;
+    /* vertices: free blocks that occur in a residual, ranked by first appearance in refine's loop
+     * (calibration.cpp:384-399: for every view, for every marker: intrinsics, pose, point) */
+    int *rank = malloc(sizeof(int) * NB), *present = calloc(NB, sizeof(int)), nr = 0;
+    for (int i = 0; i < NB; ++i) rank[i] = -1;
+    for (int v = 0; v < V; ++v)
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            const int ids[3] = { pb->cam_of_view[v], C + P + v, C + pb->point_id[o] };
+            const int free_[3] = { !pb->fix_intrinsics, 1, !pb->fix_points };
+            for (int k = 0; k < 3; ++k)
+                if (free_[k] && rank[ids[k]] < 0) { rank[ids[k]] = nr++; present[ids[k]] = 1; }
+        }
+    /* edges: every pair of free blocks of one residual block, both directions, unique */
+    size_t ne = 0, cap = 6 * (size_t)pb->N + 1;
+    long long *e = malloc(sizeof(long long) * cap);
+    for (int v = 0; v < V; ++v)
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            const int ids[3] = { pb->cam_of_view[v], C + P + v, C + pb->point_id[o] };
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+                if (a != b && present[ids[a]] && present[ids[b]]) e[ne++] = (long long)ids[a] * NB + ids[b];
+        }
+    qsort(e, ne, sizeof(long long), ib_cmp_ll);
+    size_t nu = 0;
+    for (size_t i = 0; i < ne; ++i) if (i == 0 || e[i] != e[i - 1]) e[nu++] = e[i];
+    size_t *adj_off = calloc((size_t)NB + 1, sizeof(size_t));
+    for (size_t i = 0; i < nu; ++i) adj_off[e[i] / NB + 1]++;
+    for (int i = 0; i < NB; ++i) adj_off[i + 1] += adj_off[i];
+    /* ComputeRecursiveIndependentSetOrdering: greedy independent set by ascending degree on what is left */
+    int *round = malloc(sizeof(int) * NB), left = 0, rounds = 0;
+    char *color = malloc(NB);
+    ib_vert *q = malloc(sizeof(ib_vert) * (NB ? NB : 1));
+    for (int i = 0; i < NB; ++i) { round[i] = -1; left += present[i]; }
+    while (left > 0) {
+        int nq = 0;
+        for (int i = 0; i < NB; ++i) {
+            if (!present[i]) continue;
+            int d = 0;
+            for (size_t k = adj_off[i]; k < adj_off[i + 1]; ++k) d += present[e[k] % NB];
+            q[nq].deg = d; q[nq].rank = rank[i]; q[nq].id = i; ++nq;
+            color[i] = 0;
+        }
+        qsort(q, nq, sizeof(ib_vert), ib_cmp_vert);
+        for (int j = 0; j < nq; ++j) {
+            const int i = q[j].id;
+            if (color[i]) continue;
+            color[i] = 2; round[i] = rounds;
+            for (size_t k = adj_off[i]; k < adj_off[i + 1]; ++k) { int n = (int)(e[k] % NB); if (present[n] && !color[n]) color[n] = 1; }
+        }
+        for (int j = 0; j < nq; ++j) if (color[q[j].id] == 2) { present[q[j].id] = 0; --left; }
+        ++rounds;
+    }
+    /* CoordinateDescentMinimizer::CreateOrdering reverses the sets */
+    for (int i = 0; i < NB; ++i) group[i] = round[i] < 0 ? -1 : rounds - 1 - round[i];
+    free(rank); free(present); free(e); free(adj_off); free(round); free(color); free(q);
+    return rounds;
+}
+
+/* one parameter block as an lm_model: its own residual blocks only, everything else read from the full vectors */
+typedef struct {
+    const orc_calib_problem *pb;
+    double *intr, *poses, *points;      /* the full point being improved */
+    int type, index, nfree, nglob;
+    const int *obs; int nobs;           /* IB_POINT: this point's observations */
+    const int *view_of_obs;
+    double H[81], g[9];
+} ib_ctx;
+
+static void ib_visit(ib_ctx *c, const double *xb, double *cost, double *H, double *g) {
+    const orc_calib_problem *pb = c->pb;
+    const int nf = c->nfree;
+    double s = 0;
+    if (H) { memset(H, 0, sizeof(double) * nf * nf); memset(g, 0, sizeof(double) * nf); }
+    int v0 = 0, v1 = 0, n = 0;
+    if (c->type == IB_POSE) { v0 = c->index; v1 = v0 + 1; }
+    else if (c->type == IB_CAM) { v0 = 0; v1 = pb->V; }
+    else n = c->nobs;
+    for (int v = v0; v < v1 || n > 0; ++v) {
+        int o0, o1;
+        if (c->type == IB_POINT) { o0 = 0; o1 = n; n = 0; }
+        else { if (c->type == IB_CAM && pb->cam_of_view[v] != c->index) continue; o0 = pb->view_off[v]; o1 = pb->view_off[v + 1]; }
+        for (int oo = o0; oo < o1; ++oo) {
+            const int o = c->type == IB_POINT ? c->obs[oo] : oo;
+            const int vv = c->type == IB_POINT ? c->view_of_obs[o] : v;
+            const double *in = c->type == IB_CAM ? xb : c->intr + 9 * pb->cam_of_view[vv];
+            const double *po = c->type == IB_POSE ? xb : c->poses + 6 * vv;
+            const double *X = c->type == IB_POINT ? xb : c->points + 3 * pb->point_id[o];
+            double r[2], Jc[18], Jp[12], Jx[6];
+            orc_reproj_analytic(in, po, X, pb->obs_x[o], pb->obs_y[o], r, H ? Jc : 0, H ? Jp : 0, H ? Jx : 0);
+            s += r[0] * r[0] + r[1] * r[1];
+            if (!H) continue;
+            for (int k = 0; k < 2; ++k) {
+                double row[9];
+                if (c->type == IB_CAM) for (int i = 0; i < nf; ++i) row[i] = Jc[9 * k + cam_col(pb, i)];
+                else if (c->type == IB_POSE) for (int i = 0; i < 6; ++i) row[i] = Jp[6 * k + i];
+                else for (int i = 0; i < 3; ++i) row[i] = Jx[3 * k + i];
+                for (int a = 0; a < nf; ++a) {
+                    for (int b = 0; b < nf; ++b) H[a * nf + b] += row[a] * row[b];
+                    g[a] += row[a] * r[k];
+                }
+            }
+        }
+        if (c->type == IB_POINT) break;
+    }
+    *cost = 0.5 * s;
+}
+static double ib_linearize(void *vc, const double *x, double *diag, double *grad) {
+    ib_ctx *c = vc; double cost;
+    ib_visit(c, x, &cost, c->H, c->g);
+    for (int i = 0; i < c->nfree; ++i) { diag[i] = c->H[i * c->nfree + i]; grad[i] = c->g[i]; }
+    return cost;
+}
+static int ib_solve(void *vc, const double *D, double *delta) {
+    ib_ctx *c = vc; const int nf = c->nfree;
+    double A[81];
+    memcpy(A, c->H, sizeof(double) * nf * nf);
+    for (int i = 0; i < nf; ++i) { A[i * nf + i] += D[i]; delta[i] = -c->g[i]; }
+    return orc_cholesky_solve(nf, A, delta);
+}
+static void ib_plus(void *vc, const double *x, const double *delta, double *xo) {
+    ib_ctx *c = vc;
+    memcpy(xo, x, sizeof(double) * c->nglob);
+    if (c->type == IB_CAM) for (int k = 0; k < c->nfree; ++k) xo[cam_col(c->pb, k)] += delta[k];
+    else for (int k = 0; k < c->nfree; ++k) xo[k] += delta[k];
+}
+static double ib_cost(void *vc, const double *x) { ib_ctx *c = vc; double cost; ib_visit(c, x, &cost, 0, 0); return cost; }
+static double ib_free_norm2(void *vc, const double *x) { ib_ctx *c = vc; double s = 0; for (int i = 0; i < c->nglob; ++i) s += x[i] * x[i]; return s; }
+
+static int lm_ceres(const lm_model *m, double *x, const orc_lm_options *o, orc_lm_summary *sum);
+
+double orc_calib_inner_pass(const orc_calib_problem *pb, double *intr, double *poses, double *points) {
+    const int C = pb->C, P = pb->P, V = pb->V, NB = C + P + V;
+    int *group = malloc(sizeof(int) * (NB ? NB : 1));
+    const int ng = orc_calib_inner_ordering(pb, group);
+    /* observations by point */
+    int *pt_off = calloc((size_t)P + 1, sizeof(int)), *pt_obs = malloc(sizeof(int) * (pb->N ? pb->N : 1));
+    int *view_of_obs = malloc(sizeof(int) * (pb->N ? pb->N : 1)), *fill = calloc((size_t)P + 1, sizeof(int));
+    for (int o = 0; o < pb->N; ++o) pt_off[pb->point_id[o] + 1]++;
+    for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
+    for (int v = 0; v < V; ++v)
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            const int p = pb->point_id[o];
+            pt_obs[pt_off[p] + fill[p]++] = o; view_of_obs[o] = v;
+        }
+    orc_lm_options io; lm_defaults(&io);        /* CoordinateDescentMinimizer::Solve: a default Minimizer::Options */
+    orc_lm_summary *isum = malloc(sizeof *isum);
+    for (int gi = 0; gi < ng; ++gi)
+        for (int b = 0; b < NB; ++b) {
+            if (group[b] != gi) continue;
+            ib_ctx c; memset(&c, 0, sizeof c);
+            c.pb = pb; c.intr = intr; c.poses = poses; c.points = points; c.view_of_obs = view_of_obs;
+            double *xb;
+            if (b < C) { c.type = IB_CAM; c.index = b; c.nfree = n_cam_free(pb); c.nglob = 9; xb = intr + 9 * b; }
+            else if (b < C + P) { c.type = IB_POINT; c.index = b - C; c.nfree = c.nglob = 3; xb = points + 3 * (b - C);
+                                  c.obs = pt_obs + pt_off[b - C]; c.nobs = pt_off[b - C + 1] - pt_off[b - C]; }
+            else { c.type = IB_POSE; c.index = b - C - P; c.nfree = c.nglob = 6; xb = poses + 6 * (b - C - P); }
+            double xloc[9];
+            memcpy(xloc, xb, sizeof(double) * c.nglob);
+            lm_model m = { &c, c.nfree, c.nglob, ib_linearize, ib_solve, ib_plus, ib_cost, ib_free_norm2, NULL };
+            lm_ceres(&m, xloc, &io, isum);
+            memcpy(xb, xloc, sizeof(double) * c.nglob);
+        }
+    free(group); free(pt_off); free(pt_obs); free(view_of_obs); free(fill); free(isum);
+    return orc_calib_cost(pb, intr, poses, points);
+}
+
+static double calib_m_inner(void *vc, double *x) {
+    calib_ctx *c = vc; const orc_calib_problem *pb = c->pb;
+    return orc_calib_inner_pass(pb, x, x + 9 * pb->C, x + 9 * pb->C + 6 * pb->V);
+}
+
 int orc_calib_solve(const orc_calib_problem *pb, double *intr, double *poses, double *points,
                     const orc_lm_options *opt, orc_lm_summary *sum) {
     calib_ctx c; c.pb = pb; calib_lin_alloc(&c.L, pb);
@@ -1079,7 +1285,7 @@ int orc_calib_solve(const orc_calib_problem *pb, double *intr, double *poses, do
     memcpy(x, intr, sizeof(double) * 9 * pb->C);
     memcpy(x + 9 * pb->C, poses, sizeof(double) * 6 * pb->V);
     memcpy(x + 9 * pb->C + 6 * pb->V, points, sizeof(double) * 3 * pb->P);
-    lm_model m = { &c, c.L.ns + 6 * pb->V, ng, calib_m_linearize, calib_m_solve, calib_m_plus, calib_m_cost, calib_m_free_norm2 };
+    lm_model m = { &c, c.L.ns + 6 * pb->V, ng, calib_m_linearize, calib_m_solve, calib_m_plus, calib_m_cost, calib_m_free_norm2, calib_m_inner };
     int term = (opt->strategy == 1) ? lm_nielsen(&m, x, opt, sum) : lm_ceres(&m, x, opt, sum);
     memcpy(intr, x, sizeof(double) * 9 * pb->C);
     memcpy(poses, x + 9 * pb->C, sizeof(double) * 6 * pb->V);

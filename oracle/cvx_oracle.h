@@ -90,6 +90,8 @@ typedef struct {
     int nonmonotonic;
     int max_consecutive_nonmonotonic_steps;
     double tau, eps1, eps2, eps3;   /* Nielsen: lm_core.c:128-141 */
+    int inner_iterations;           /* Solver::Options::use_inner_iterations (calibration.cpp:424) */
+    double inner_iteration_tolerance;   /* Ceres default 1e-3 */
 } orc_lm_options;
 
 #define ORC_TRACE_MAX 1024
@@ -106,6 +108,7 @@ typedef struct {
     double trace_accepted[ORC_TRACE_MAX];  /* 1/0 */
     double trace_damping[ORC_TRACE_MAX];   /* radius (Ceres) or mu (Nielsen) used for the solve */
     double trace_gradient[ORC_TRACE_MAX];  /* max-norm of gradient at the linearisation point */
+    int num_inner_iteration_steps;         /* outer iterations whose candidate went through inner iterations */
 } orc_lm_summary;
 
 void orc_lm_options_refine(orc_lm_options *o);   /* calibration.cpp:420-428 + Ceres defaults */
@@ -142,6 +145,18 @@ int orc_calib_solve(const orc_calib_problem *pb, double *intr, double *poses, do
                     const orc_lm_options *opt, orc_lm_summary *sum);
 /* the value CameraCalibration::refine returns: sqrt(total_cost / (2N)), calibration.cpp:463 */
 double orc_calib_refine_return(double total_cost, int N);
+/* Inner iterations (use_inner_iterations = true, calibration.cpp:424; no inner_iteration_ordering is given, so
+ * Ceres builds one: CoordinateDescentMinimizer::CreateOrdering = recursive greedy independent sets of the Hessian
+ * graph by ascending degree, reversed).  Restated from Ceres' published algorithm, PARITY UNPINNED.
+ * group[C + P + V]: block ids are camera c -> c, point p -> C + p, pose v -> C + P + v; the value is the position
+ * of the block's independent set in the order the sets are minimised (0 first), -1 for a block that is constant or
+ * in no residual.  Ties of degree are broken by the order in which refine's AddResidualBlock calls first name the
+ * blocks (Ceres breaks them by address).  Returns the number of sets. */
+int orc_calib_inner_ordering(const orc_calib_problem *pb, int *group);
+/* one pass of CoordinateDescentMinimizer::Minimize over x = (intr, poses, points) in place: every block of every
+ * set in turn is minimised over its own residuals, all other blocks held, by the trust-region LM with Ceres'
+ * default options; returns the cost of the whole problem afterwards */
+double orc_calib_inner_pass(const orc_calib_problem *pb, double *intr, double *poses, double *points);
 
 /* ---- hand-eye ------------------------------------------------------------ */
 typedef struct {

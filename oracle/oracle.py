@@ -34,7 +34,8 @@ class LMOptions(C.Structure):
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("jacobi_scaling", C.c_int), ("nonmonotonic", C.c_int),
                 ("max_consecutive_nonmonotonic_steps", C.c_int),
-                ("tau", C.c_double), ("eps1", C.c_double), ("eps2", C.c_double), ("eps3", C.c_double)]
+                ("tau", C.c_double), ("eps1", C.c_double), ("eps2", C.c_double), ("eps3", C.c_double),
+                ("inner_iterations", C.c_int), ("inner_iteration_tolerance", C.c_double)]
 
 
 class LMSummary(C.Structure):
@@ -42,7 +43,8 @@ class LMSummary(C.Structure):
                 ("termination", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("trace_len", C.c_int),
                 ("trace_cost", C.c_double * TRACE_MAX), ("trace_accepted", C.c_double * TRACE_MAX),
-                ("trace_damping", C.c_double * TRACE_MAX), ("trace_gradient", C.c_double * TRACE_MAX)]
+                ("trace_damping", C.c_double * TRACE_MAX), ("trace_gradient", C.c_double * TRACE_MAX),
+                ("num_inner_iteration_steps", C.c_int)]
 
     def trace(self):
         n = self.trace_len
@@ -105,6 +107,8 @@ def lib():
         L.orc_calib_solve.argtypes = [pp, dp, dp, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]
         L.orc_calib_solve.restype = C.c_int
         L.orc_calib_refine_return.argtypes = [C.c_double, C.c_int]; L.orc_calib_refine_return.restype = C.c_double
+        L.orc_calib_inner_ordering.argtypes = [pp, ip]; L.orc_calib_inner_ordering.restype = C.c_int
+        L.orc_calib_inner_pass.argtypes = [pp, dp, dp, dp]; L.orc_calib_inner_pass.restype = C.c_double
         hp = C.POINTER(HandEyeProblem)
         L.orc_handeye_cost.argtypes = [hp, dp]; L.orc_handeye_cost.restype = C.c_double
         L.orc_handeye_normal_eq.argtypes = [hp, dp, dp, dp, dp]
@@ -211,6 +215,18 @@ class Calib:
         lib().orc_calib_reduced_system(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points), _dp(Dp), _dp(Ds),
                                        _dp(S), _dp(g), C.byref(cost))
         return S, g, cost.value
+
+    def inner_ordering(self):
+        """(group per block [C + P + V], number of independent sets) of Ceres' automatic inner-iteration ordering"""
+        g = np.zeros(self.C + self.P + self.V, dtype=np.int32)
+        n = lib().orc_calib_inner_ordering(C.byref(self.pb), _ip(g))
+        return g, n
+
+    def inner_pass(self, intr, poses, points):
+        """one coordinate-descent pass of the inner iterations; returns the new (intr, poses, points, cost)"""
+        intr, poses, points = f64(intr).copy(), f64(poses).copy(), f64(points).copy()
+        c = lib().orc_calib_inner_pass(C.byref(self.pb), _dp(intr), _dp(poses), _dp(points))
+        return intr, poses, points, c
 
     def solve(self, intr, poses, points, options):
         intr, poses, points = f64(intr).copy(), f64(poses).copy(), f64(points).copy()
