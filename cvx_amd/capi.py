@@ -44,7 +44,8 @@ class LMOptions(C.Structure):
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("jacobi_scaling", C.c_int), ("nonmonotonic", C.c_int),
                 ("max_consecutive_nonmonotonic_steps", C.c_int),
-                ("tau", C.c_double), ("eps1", C.c_double), ("eps2", C.c_double), ("eps3", C.c_double)]
+                ("tau", C.c_double), ("eps1", C.c_double), ("eps2", C.c_double), ("eps3", C.c_double),
+                ("inner_iterations", C.c_int), ("inner_iteration_tolerance", C.c_double)]
 
 
 class LMSummary(C.Structure):
@@ -53,7 +54,7 @@ class LMSummary(C.Structure):
                 ("trace_len", C.c_int),
                 ("trace_cost", C.c_double * TRACE_MAX), ("trace_accepted", C.c_double * TRACE_MAX),
                 ("trace_damping", C.c_double * TRACE_MAX), ("trace_gradient", C.c_double * TRACE_MAX),
-                ("seconds_total", C.c_double)]
+                ("seconds_total", C.c_double), ("num_inner_iteration_steps", C.c_int)]
 
     def trace(self):
         n = self.trace_len
@@ -104,6 +105,8 @@ SIGNATURES = {
     "cvx_calib_get_params": (C.c_int, [C.c_void_p, dp, dp, dp]),
     "cvx_calib_num_shared": (C.c_int, [C.c_void_p]),
     "cvx_calib_cost": (C.c_int, [C.c_void_p, dp]),
+    "cvx_calib_inner_pass": (C.c_int, [C.c_void_p, dp]),
+    "cvx_calib_inner_ordering": (C.c_int, [C.c_int, C.c_int, C.c_int, ip, ip, ip, C.c_int, C.c_int, ip, ip]),
     "cvx_calib_evaluate": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp]),
     "cvx_calib_evaluate_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cvx_calib_init_scaling": (C.c_int, [C.c_void_p, C.c_int]),

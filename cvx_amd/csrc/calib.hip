@@ -14,6 +14,7 @@
 #include "lm_driver.h"
 #include "solve_kernels.h"
 #include "step_kernels.h"
+#include "inner_kernels.h"
 
 using namespace cvxk;
 
@@ -90,6 +91,13 @@ struct cvx_calib {
     int *d_fail = nullptr;
     size_t fin_lds = 0;
     std::vector<double> s2_shared, h_tail, h_A;
+    // inner iterations (inner_kernels.h), made on first use
+    bool inner_ready = false;
+    int inner_sets = 0;
+    std::vector<int> inner_types;    // per set: bit t set when the set holds blocks of type t (camera, point, pose)
+    int *d_pt_off = nullptr, *d_pt_obs = nullptr, *d_blk_group = nullptr, *d_ib_flag = nullptr, *d_ib_active = nullptr;
+    double *d_ib_H = nullptr, *d_ib_st = nullptr, *d_ib_xc = nullptr, *d_ib_cc = nullptr, *d_ib_slab = nullptr, *d_ib_out = nullptr;
+    int *h_ib_active = nullptr;
     // exchange
     cvx_allreduce_fn xfn = nullptr;
     void *xctx = nullptr;
@@ -111,12 +119,14 @@ cvx_calib::~cvx_calib() {
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
-                    d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X};
+                    d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_pt_off, d_pt_obs, d_blk_group,
+                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
     if (h_ds_emb) (void)hipHostFree(h_ds_emb);
     if (h_E2) (void)hipHostFree(h_E2);
+    if (h_ib_active) (void)hipHostFree(h_ib_active);
     if (ev_made)
         for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
     if (ev_step) (void)hipEventDestroy(ev_step);
@@ -298,6 +308,119 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
     return CVX_OK;
 }
 
+// 1/2 sum r^2 of parameter buffer `which` over this rank's observations
+int cost_of(cvx_calib *h, int which, double *cost) {
+    int st = launch_pose_prepare(h, which);
+    if (st) return st;
+    hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
+                       h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[which], h->d_points[which], h->d_rt[which],
+                       (long long)h->N, h->d_cost_partial);
+    CVX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
+                       h->d_out_view, 0, h->d_E2, (double *)nullptr, 0.0);
+    CVX_HIP(hipGetLastError());
+    CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    *cost = 0.5 * h->h_E2[0];
+    return CVX_OK;
+}
+
+// ---- inner iterations (calibration.cpp:424): ordering, per-point observation lists and block state, on first use
+int ensure_inner(cvx_calib *h) {
+    if (h->inner_ready) return CVX_OK;
+    const int C = h->C, P = h->P, V = h->V, NB = C + P + V;
+    std::vector<int> point_id((size_t)h->N);
+    if (h->N) CVX_HIP(hipMemcpyAsync(point_id.data(), h->d_point_id, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> group(NB);
+    int st = cvx_calib_inner_ordering(C, V, P, h->h_cam_of_view.data(), h->h_view_off.data(), point_id.data(), h->fix_intr,
+                                      h->fix_pts, group.data(), &h->inner_sets);
+    if (st) return st;
+    h->inner_types.assign(h->inner_sets, 0);
+    for (int i = 0; i < NB; ++i)
+        if (group[i] >= 0) h->inner_types[group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
+    std::vector<int> pt_off((size_t)P + 1, 0), pt_obs((size_t)h->N);
+    for (int64_t o = 0; o < h->N; ++o) pt_off[point_id[o] + 1]++;
+    for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
+    {
+        std::vector<int> pos(pt_off.begin(), pt_off.end() - 1);
+        for (int64_t o = 0; o < h->N; ++o) pt_obs[pos[point_id[o]]++] = (int)o;      // ascending observation = ascending view
+    }
+    hipStream_t s = h->stream;
+    st = dev_upload(&h->d_pt_off, pt_off.data(), pt_off.size(), s); if (st) return st;
+    st = dev_upload(&h->d_pt_obs, pt_obs.data(), pt_obs.size(), s); if (st) return st;
+    st = dev_upload(&h->d_blk_group, group.data(), group.size(), s); if (st) return st;
+    st = dev_alloc(&h->d_ib_flag, 4 * (size_t)NB); if (st) return st;
+    st = dev_alloc(&h->d_ib_active, 1); if (st) return st;
+    st = dev_alloc(&h->d_ib_H, (size_t)NB * cvxi::IB_STRIDE); if (st) return st;
+    st = dev_alloc(&h->d_ib_st, (size_t)NB * cvxi::IB_STATE); if (st) return st;
+    st = dev_alloc(&h->d_ib_xc, 9 * (size_t)NB); if (st) return st;
+    st = dev_alloc(&h->d_ib_cc, (size_t)NB); if (st) return st;
+    st = dev_alloc(&h->d_ib_slab, (size_t)std::max(1, h->n_groups) * cvxi::IB_STRIDE); if (st) return st;
+    st = dev_alloc(&h->d_ib_out, 4); if (st) return st;
+    CVX_HIP(hipMemsetAsync(h->d_ib_flag, 0, 4 * (size_t)NB * sizeof(int), s));
+    CVX_HIP(hipMemsetAsync(h->d_ib_st, 0, (size_t)NB * cvxi::IB_STATE * sizeof(double), s));
+    CVX_HIP(hipHostMalloc((void **)&h->h_ib_active, 4 * sizeof(int), hipHostMallocDefault));
+    CVX_HIP(hipStreamSynchronize(s));       // the uploads read host vectors that end here
+    h->inner_ready = true;
+    return CVX_OK;
+}
+
+// One pass of CoordinateDescentMinimizer::Minimize on parameter buffer `which`, in place: set after set, every
+// block of the set advances one LM iteration per round until none goes on (at most 50 iterations each, plus the
+// rounds a block spends on invalid steps: bounded by the round limit below)
+int inner_pass(cvx_calib *h, int which) {
+    if (h->nranks > 1) {
+        cvx::set_last_error("inner iterations need all observations of a block on one rank");
+        return CVX_ERR_UNSUPPORTED;
+    }
+    int st = ensure_inner(h);
+    if (st) return st;
+    const int NB = h->C + h->P + h->V;
+    cvxi::InnerArgs a;
+    a.view_off = h->d_view_off; a.cam_of_view = h->d_cam_of_view; a.point_id = h->d_point_id; a.view_id = h->d_view_id;
+    a.obs_x = h->d_obs_x; a.obs_y = h->d_obs_y; a.pt_off = h->d_pt_off; a.pt_obs = h->d_pt_obs;
+    a.grp_v0 = h->d_grp_v0; a.glist = h->d_glist; a.glist_off = h->d_glist_off;
+    a.intr = h->d_intr[which]; a.points = h->d_points[which]; a.poses = h->d_poses[which]; a.rt = h->d_rt[which];
+    a.blk_group = h->d_blk_group; a.H = h->d_ib_H; a.st = h->d_ib_st; a.xc = h->d_ib_xc; a.cc = h->d_ib_cc;
+    a.flag = h->d_ib_flag; a.cam_slab = h->d_ib_slab; a.active = h->d_ib_active;
+    a.C = h->C; a.P = h->P; a.V = h->V; a.ncf = h->ncf; a.fix_k3 = h->fix_k3; a.n_view_groups = h->n_groups;
+    const dim3 per_block((NB + 63) / 64), t64(64);
+    for (int set = 0; set < h->inner_sets; ++set) {
+        const int types = h->inner_types[set];
+        const bool cams = types & (1 << cvxi::IB_CAM), pts = types & (1 << cvxi::IB_POINT), poses = types & (1 << cvxi::IB_POSE);
+        if (cams || pts) {                  // they read the rotation tables of the point being improved
+            st = launch_pose_prepare(h, which);
+            if (st) return st;
+        }
+        a.cur = set;
+        hipLaunchKernelGGL(cvxi::k_inner_reset, per_block, t64, 0, h->stream, a);
+        for (int round = 0;; ++round) {
+            if (round > 60) { cvx::set_last_error("inner iterations: a block did not terminate"); return CVX_ERR_NUMERIC; }
+            if (poses) hipLaunchKernelGGL(cvxi::k_inner_pose<0>, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, a);
+            if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<0>, dim3(h->P), dim3(cvxi::IP_THREADS), 0, h->stream, a);
+            if (cams) {
+                hipLaunchKernelGGL(cvxi::k_inner_cam<0>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
+                hipLaunchKernelGGL(cvxi::k_inner_cam_sum<0>, dim3(h->C), t64, 0, h->stream, a);
+            }
+            hipLaunchKernelGGL(cvxi::k_inner_solve, per_block, t64, 0, h->stream, a);
+            if (poses) hipLaunchKernelGGL(cvxi::k_inner_pose<1>, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, a);
+            if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<1>, dim3(h->P), dim3(cvxi::IP_THREADS), 0, h->stream, a);
+            if (cams) {
+                hipLaunchKernelGGL(cvxi::k_inner_cam<1>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
+                hipLaunchKernelGGL(cvxi::k_inner_cam_sum<1>, dim3(h->C), t64, 0, h->stream, a);
+            }
+            hipLaunchKernelGGL(cvxi::k_inner_decide, per_block, t64, 0, h->stream, a);
+            CVX_HIP(hipGetLastError());
+            CVX_HIP(hipMemcpyAsync(h->h_ib_active, h->d_ib_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            CVX_HIP(hipStreamSynchronize(h->stream));
+            if (h->h_ib_active[0] == 0) break;
+        }
+        if (poses) h->rt_valid[which] = false;
+    }
+    return CVX_OK;
+}
+
 class CalibEvaluator : public cvx::Evaluator {
 public:
     explicit CalibEvaluator(cvx_calib *h_) : h(h_) {}
@@ -378,6 +501,22 @@ public:
 
     int accept() override {
         h->cur = 1 - h->cur;
+        return CVX_OK;
+    }
+
+    // the candidate of the last try_step goes through one inner-iteration pass
+    int inner_iterations(double *cost, double *step_norm2) override {
+        const int nxt = 1 - h->cur;
+        int st = inner_pass(h, nxt);
+        if (st) return st;
+        hipLaunchKernelGGL(cvxi::k_inner_step_norm, dim3(1), dim3(1024), 0, h->stream, h->d_intr[h->cur], h->d_intr[nxt],
+                           9LL * h->C, h->d_points[h->cur], h->d_points[nxt], 3LL * h->P, h->d_poses[h->cur], h->d_poses[nxt],
+                           6LL * h->V, h->d_ib_out);
+        CVX_HIP(hipGetLastError());
+        CVX_HIP(hipMemcpyAsync(h->h_ib_active + 2, h->d_ib_out, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        st = cost_of(h, nxt, cost);         // synchronises the stream
+        if (st) return st;
+        std::memcpy(step_norm2, h->h_ib_active + 2, sizeof(double));
         return CVX_OK;
     }
 
@@ -770,19 +909,18 @@ extern "C" int cvx_calib_num_shared(const cvx_calib *h) { return h ? h->ns : -1;
 extern "C" int cvx_calib_cost(cvx_calib *h, double *cost) {
     if (!h || !cost) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
-    int st = launch_pose_prepare(h, h->cur);
+    return cost_of(h, h->cur, cost);
+}
+
+extern "C" int cvx_calib_inner_pass(cvx_calib *h, double *cost) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    int st = inner_pass(h, h->cur);
     if (st) return st;
-    hipLaunchKernelGGL(k_cost, dim3(h->n_cost_blocks), dim3(256), 0, h->stream, h->d_view_id, h->d_cam_of_view,
-                       h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_intr[h->cur], h->d_points[h->cur], h->d_rt[h->cur],
-                       (long long)h->N, h->d_cost_partial);
-    CVX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, h->n_cost_blocks,
-                       h->d_out_view, 0, h->d_E2, (double *)nullptr, 0.0);
-    CVX_HIP(hipGetLastError());
-    CVX_HIP(hipMemcpyAsync(h->h_E2, h->d_E2, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    CVX_HIP(hipStreamSynchronize(h->stream));
-    *cost = 0.5 * h->h_E2[0];
-    return CVX_OK;
+    double c = 0;
+    st = cost_of(h, h->cur, &c);
+    if (cost) *cost = c;
+    return st;
 }
 
 extern "C" int cvx_calib_evaluate_device(cvx_calib *h, void **device_buffer) {

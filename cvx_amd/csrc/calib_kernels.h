@@ -27,11 +27,9 @@ constexpr int AROW = 17;         // LDS stride (doubles) of one staged Jacobian 
 // K0: per-view rotation matrix and its derivative w.r.t. the global angle-axis vector
 // (both branches of ceres::AngleAxisRotatePoint, used at calibration.cpp:286)
 // -----------------------------------------------------------------------------------------
-__global__ void k_pose_prepare(const double *__restrict__ poses, double *__restrict__ rt, int V) {
-    int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    const double w0 = poses[6 * v], w1 = poses[6 * v + 1], w2 = poses[6 * v + 2];
-    double *o = rt + (size_t)v * RT_STRIDE;
+// o[40] = R[9] | dR/dw_j [3][9] | t[3] | 0 for the pose (angle-axis, t)
+__device__ __forceinline__ void pose_table(const double *__restrict__ pose, double *__restrict__ o) {
+    const double w0 = pose[0], w1 = pose[1], w2 = pose[2];
     const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
     double R[9], dR[3][9];
     if (th2 > 2.220446049250313e-16) {
@@ -63,10 +61,16 @@ __global__ void k_pose_prepare(const double *__restrict__ poses, double *__restr
     for (int i = 0; i < 9; ++i) o[i] = R[i];
     for (int j = 0; j < 3; ++j)
         for (int i = 0; i < 9; ++i) o[9 + 9 * j + i] = dR[j][i];
-    o[36] = poses[6 * v + 3];
-    o[37] = poses[6 * v + 4];
-    o[38] = poses[6 * v + 5];
+    o[36] = pose[3];
+    o[37] = pose[4];
+    o[38] = pose[5];
     o[39] = 0.0;
+}
+
+__global__ void k_pose_prepare(const double *__restrict__ poses, double *__restrict__ rt, int V) {
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    pose_table(poses + 6 * v, rt + (size_t)v * RT_STRIDE);
 }
 
 struct Intr {

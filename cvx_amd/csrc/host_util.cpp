@@ -312,6 +312,92 @@ extern "C" int cvx_handeye_pairs_moving(int n, const double *G, const double *Tt
     return CVX_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Ordering of the inner iterations: what CoordinateDescentMinimizer::CreateOrdering makes of the Hessian graph of
+// refine's problem when Solver::Options::inner_iteration_ordering is left empty (calibration.cpp:420-428).
+// Vertices: the free parameter blocks that occur in a residual block; edges: blocks that share one.  The graph is
+// tripartite (camera -- pose -- point -- camera) and is never built: a vertex's neighbours are enumerated from the
+// observation lists (a pose's own observations, a point's observations by view, a camera's views and the points it
+// sees), so a round costs O(observations).
+// ---------------------------------------------------------------------------------------
+extern "C" int cvx_calib_inner_ordering(int C, int V, int P, const int *cam_of_view, const int *view_off,
+                                        const int *point_id, int fix_intrinsics, int fix_points, int *group, int *n_sets) {
+    if (C < 1 || V < 0 || P < 1 || !cam_of_view || !view_off || !group || !n_sets) return CVX_ERR_INVALID_ARG;
+    const int NB = C + P + V;
+    const int64_t N = V ? view_off[V] : 0;
+    if (N > 0 && !point_id) return CVX_ERR_INVALID_ARG;
+    // observations by point; which camera sees which point; the views of a camera
+    std::vector<int64_t> pt_off((size_t)P + 1, 0);
+    for (int64_t o = 0; o < N; ++o) {
+        if (point_id[o] < 0 || point_id[o] >= P) return CVX_ERR_INVALID_ARG;
+        pt_off[point_id[o] + 1]++;
+    }
+    for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
+    std::vector<int> pt_view((size_t)N);
+    std::vector<char> sees((size_t)C * P, 0);
+    std::vector<std::vector<int>> cam_views(C);
+    {
+        std::vector<int64_t> pos(pt_off.begin(), pt_off.end() - 1);
+        for (int v = 0; v < V; ++v) {
+            const int c = cam_of_view[v];
+            if (c < 0 || c >= C) return CVX_ERR_INVALID_ARG;
+            if (view_off[v + 1] > view_off[v]) cam_views[c].push_back(v);
+            for (int o = view_off[v]; o < view_off[v + 1]; ++o) { pt_view[pos[point_id[o]]++] = v; sees[(size_t)c * P + point_id[o]] = 1; }
+        }
+    }
+    // rank: the order in which refine's loop first names the blocks (intrinsics, pose, point per marker)
+    std::vector<int> rank(NB, -1);
+    std::vector<char> present(NB, 0);
+    int nr = 0, left = 0;
+    for (int v = 0; v < V; ++v)
+        for (int o = view_off[v]; o < view_off[v + 1]; ++o) {
+            const int ids[3] = {cam_of_view[v], C + P + v, C + point_id[o]};
+            const bool is_free[3] = {!fix_intrinsics, true, !fix_points};
+            for (int k = 0; k < 3; ++k)
+                if (is_free[k] && rank[ids[k]] < 0) { rank[ids[k]] = nr++; present[ids[k]] = 1; ++left; }
+        }
+    auto for_neighbours = [&](int id, auto &&f) {
+        if (id < C) {
+            for (int v : cam_views[id]) f(C + P + v);
+            for (int p = 0; p < P; ++p) if (sees[(size_t)id * P + p]) f(C + p);
+        } else if (id < C + P) {
+            const int p = id - C;
+            for (int64_t k = pt_off[p]; k < pt_off[p + 1]; ++k) f(C + P + pt_view[k]);
+            for (int c = 0; c < C; ++c) if (sees[(size_t)c * P + p]) f(c);
+        } else {
+            const int v = id - C - P;
+            f(cam_of_view[v]);
+            for (int o = view_off[v]; o < view_off[v + 1]; ++o) f(C + point_id[o]);
+        }
+    };
+    std::vector<int> round(NB, -1);
+    struct Vert { int deg, rank, id; };
+    std::vector<Vert> q;
+    std::vector<char> color(NB);
+    int rounds = 0;
+    while (left > 0) {
+        q.clear();
+        for (int i = 0; i < NB; ++i) {
+            if (!present[i]) continue;
+            int d = 0;
+            for_neighbours(i, [&](int n) { d += present[n]; });
+            q.push_back({d, rank[i], i});
+            color[i] = 0;
+        }
+        std::sort(q.begin(), q.end(), [](const Vert &a, const Vert &b) { return a.deg != b.deg ? a.deg < b.deg : a.rank < b.rank; });
+        for (const Vert &x : q) {
+            if (color[x.id]) continue;
+            color[x.id] = 2; round[x.id] = rounds;
+            for_neighbours(x.id, [&](int n) { if (present[n] && !color[n]) color[n] = 1; });
+        }
+        for (const Vert &x : q) if (color[x.id] == 2) { present[x.id] = 0; --left; }
+        ++rounds;
+    }
+    for (int i = 0; i < NB; ++i) group[i] = round[i] < 0 ? -1 : rounds - 1 - round[i];      // CreateOrdering reverses
+    *n_sets = rounds;
+    return CVX_OK;
+}
+
 extern "C" int cvx_partition_views(int n_views, const int *view_off, int nranks, int *first_view) {
     if (n_views < 0 || !view_off || nranks < 1 || !first_view) return CVX_ERR_INVALID_ARG;
     const long long total = view_off[n_views];

@@ -35,6 +35,7 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
     const int max_nonmono = o.nonmonotonic ? o.max_consecutive_nonmonotonic_steps : 0;
     int term = 0, invalid_run = 0, it = 0;
     bool need_gcheck = false;   // the gradient at the current point has not been tested yet
+    bool inner_enabled = o.inner_iterations != 0;
     // lowest-cost point visited: the current one until an uphill step is accepted
     double best_cost = cost;
     bool best_is_current = true;
@@ -67,8 +68,22 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
             continue;
         }
         invalid_run = 0;
-        const double cand = s.cand_cost;
-        const double sn = std::sqrt(s.step_norm2), xn = std::sqrt(s.x_norm2);
+        double cand = s.cand_cost, model_change = s.model_change, step_norm2 = s.step_norm2;
+        bool inner_useful = false;
+        if (inner_enabled && std::isfinite(cand)) {
+            // TrustRegionMinimizer::DoInnerIterationsIfNeeded: what the pass gains is credited to the model, and
+            // the passes stop for good once one gains less than the tolerance
+            double inner_cost = 0, n2 = 0;
+            const int st = ev.inner_iterations(&inner_cost, &n2);
+            if (st) return st;
+            sum.num_inner_iteration_steps++;
+            model_change += cand - inner_cost;
+            inner_useful = inner_cost < cost;
+            inner_enabled = (1.0 - inner_cost / cand) > o.inner_iteration_tolerance;
+            cand = inner_cost;
+            step_norm2 = n2;
+        }
+        const double sn = std::sqrt(step_norm2), xn = std::sqrt(s.x_norm2);
         if (sn <= o.parameter_tolerance * (xn + o.parameter_tolerance)) {
             trace_push(sum, cand, 0, radius, gmax);
             term = 2;
@@ -79,10 +94,10 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
             term = 3;
             break;
         }
-        const double rel = (ev_cur - cand) / s.model_change;
-        const double hist = (ev_ref - cand) / (ev_acc_ref + s.model_change);
+        const double rel = (ev_cur - cand) / model_change;
+        const double hist = (ev_ref - cand) / (ev_acc_ref + model_change);
         const double rho = (max_nonmono > 0 && hist > rel) ? hist : rel;
-        if (rho > o.min_relative_decrease) {
+        if (inner_useful || rho > o.min_relative_decrease) {      // IsStepSuccessful
             trace_push(sum, cand, 1, radius, gmax);
             if (cand < best_cost) {
                 best_cost = cand; best_is_current = true;
@@ -100,7 +115,7 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
             radius = radius / f;
             if (radius > o.max_radius) radius = o.max_radius;
             decrease_factor = 2.0;
-            ev_cur = cand; ev_acc_cand += s.model_change; ev_acc_ref += s.model_change;
+            ev_cur = cand; ev_acc_cand += model_change; ev_acc_ref += model_change;
             if (ev_cur < ev_min) { ev_min = ev_cur; ev_nonmono = 0; ev_cand = ev_cur; ev_acc_cand = 0; }
             else { ++ev_nonmono; if (ev_cur > ev_cand) { ev_cand = ev_cur; ev_acc_cand = 0; } }
             if (ev_nonmono == max_nonmono) { ev_ref = ev_cand; ev_acc_ref = ev_acc_cand; }
@@ -210,6 +225,8 @@ static void lm_defaults(cvx_lm_options *o) {
     o->max_consecutive_nonmonotonic_steps = 5;
     o->tau = 1e-3;                   // levmar.h:90-91
     o->eps1 = o->eps2 = o->eps3 = 1e-17;
+    o->inner_iterations = 0;
+    o->inner_iteration_tolerance = 1e-3;
 }
 
 extern "C" void cvx_lm_options_refine(cvx_lm_options *o) {

@@ -5,8 +5,9 @@
 //   strategy 0: the trust-region LM that ceres::Solve runs for
 //               /root/reference/modules/calib/src/calibration.cpp:420-433 and handeye.cpp:310-322
 //               (TrustRegionMinimizer + LevenbergMarquardtStrategy + TrustRegionStepEvaluator;
-//                Ceres is un-vendored, restated from its published algorithm, inner iterations
-//                excluded);
+//                Ceres is un-vendored, restated from its published algorithm; inner iterations as
+//                DoInnerIterationsIfNeeded / IsStepSuccessful use them, the pass itself is the
+//                evaluator's);
 //   strategy 1: levmar's dlevmar_der loop,
 //               /root/reference/modules/util/src/3rdparty/levmar/lm_core.c:163-409.
 #pragma once
@@ -52,6 +53,9 @@ public:
     // makes that copy the current point again.
     virtual int save_best() = 0;
     virtual int restore_best() = 0;
+    // One inner-iteration pass (CoordinateDescentMinimizer::Minimize) on the last candidate, in place: *cost = its
+    // cost afterwards, *step_norm2 = |x - candidate|^2 afterwards.  Evaluators without one refuse.
+    virtual int inner_iterations(double *cost, double *step_norm2) { (void)cost; (void)step_norm2; return CVX_ERR_UNSUPPORTED; }
 };
 
 int lm_minimize(Evaluator &ev, const cvx_lm_options &opt, cvx_lm_summary &sum);

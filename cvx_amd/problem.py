@@ -53,6 +53,12 @@ class Calib:
         check(lib().cvx_calib_cost(self.h, C.byref(c)), "cost")
         return c.value
 
+    def inner_pass(self):
+        """one coordinate-descent pass of Ceres' inner iterations on the current parameters; returns the cost"""
+        c = C.c_double()
+        check(lib().cvx_calib_inner_pass(self.h, C.byref(c)), "inner_pass")
+        return c.value
+
     def evaluate(self):
         r = np.zeros((self.N, 2)); Jc = np.zeros((self.N, 2, 9)); Jp = np.zeros((self.N, 2, 6)); Jx = np.zeros((self.N, 2, 3))
         c = C.c_double()
@@ -108,6 +114,16 @@ class Calib:
         check(lib().cvx_calib_geometry(self.h, g), "geometry")
         return {"ZC": g[0], "ns": g[1], "n_groups": g[2], "n_chunks": g[3], "tile_pairs": g[4], "threads": g[5],
                 "z_rows": g[6]}
+
+
+def inner_ordering(cam_of_view, view_off, point_id, n_cameras, n_points, fix_intrinsics=False, fix_points=False):
+    """(group per block [cameras | points | poses], number of sets) of the automatic inner-iteration ordering"""
+    cam_of_view, view_off, point_id = i32(cam_of_view), i32(view_off), i32(point_id)
+    V = len(cam_of_view)
+    g = np.zeros(int(n_cameras) + int(n_points) + V, dtype=np.int32); n = C.c_int()
+    check(lib().cvx_calib_inner_ordering(int(n_cameras), V, int(n_points), pi(cam_of_view), pi(view_off), pi(point_id),
+                                         int(fix_intrinsics), int(fix_points), pi(g), C.byref(n)), "inner_ordering")
+    return g, n.value
 
 
 class HandEye:

@@ -61,6 +61,9 @@ typedef struct {
     int nonmonotonic;
     int max_consecutive_nonmonotonic_steps;
     double tau, eps1, eps2, eps3;
+    int inner_iterations;               /* Solver::Options::use_inner_iterations (calibration.cpp:424); strategy 0,
+                                           calibration handles only: other solves return CVX_ERR_UNSUPPORTED with it */
+    double inner_iteration_tolerance;   /* Ceres default 1e-3 */
 } cvx_lm_options;
 
 #define CVX_TRACE_MAX 1024
@@ -76,12 +79,16 @@ typedef struct {
     double trace_damping[CVX_TRACE_MAX];   /* radius (strategy 0) or mu (strategy 1) */
     double trace_gradient[CVX_TRACE_MAX];  /* max-norm gradient at the linearisation point */
     double seconds_total;                  /* wall time inside the solve */
+    int num_inner_iteration_steps;         /* linear solves whose candidate went through an inner-iteration pass */
 } cvx_lm_summary;
 
-/* calibration.cpp:420-428.  Deviations from what ceres::Solve does with those options (the
- * reference holds no vectors for this loop, parity unpinned): linear solves are exact (the reference's
- * ITERATIVE_SCHUR + SCHUR_JACOBI conjugate gradients are inexact), and use_inner_iterations is not restated.
- * Non-monotonic steps are, including that the solve hands back the lowest-cost point it visited. */
+/* calibration.cpp:420-428, use_inner_iterations (:424) included.  Deviation from what ceres::Solve does with those
+ * options (the reference holds no vectors for this loop, parity unpinned): linear solves are
+ * exact (the reference's ITERATIVE_SCHUR + SCHUR_JACOBI conjugate gradients are inexact).  Non-monotonic steps are
+ * restated, including that the solve hands back the lowest-cost point it visited; inner iterations are, with the
+ * ordering Ceres builds when none is given (cvx_calib_inner_ordering).  Inner iterations need all observations of
+ * a block on one rank: a view-sharded handle (cvx_calib_set_exchange with nranks > 1) returns CVX_ERR_UNSUPPORTED
+ * for them -- clear the flag there. */
 void cvx_lm_options_refine(cvx_lm_options *o);
 void cvx_lm_options_handeye(cvx_lm_options *o);  /* handeye.cpp:310-319 */
 void cvx_lm_options_levmar(cvx_lm_options *o);   /* lm.hpp:43-50,61 */
@@ -183,6 +190,21 @@ int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *ctx, int ran
 
 /* the whole LM solve (ceres::Solve at calibration.cpp:433); parameters are updated in place */
 int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *summary);
+
+/* Inner iterations (use_inner_iterations, calibration.cpp:424).  The reference gives no inner_iteration_ordering,
+ * so Ceres makes one (CoordinateDescentMinimizer::CreateOrdering: greedy independent sets of the Hessian graph by
+ * ascending degree, recursively on what is left, then reversed).  group[n_cameras + n_points + n_views] receives,
+ * for camera c at [c], point p at [n_cameras + p], pose v at [n_cameras + n_points + v], the position of the
+ * block's set in the order the sets are minimised, or -1 for a block that is constant or occurs in no residual;
+ * *n_sets the number of sets.  Degree ties go to the block refine's AddResidualBlock loop (:384-399) names first
+ * (Ceres: lowest address).  Host only. */
+int cvx_calib_inner_ordering(int n_cameras, int n_views, int n_points, const int *cam_of_view, const int *view_off,
+                             const int *point_id, int fix_intrinsics, int fix_points, int *group, int *n_sets);
+/* One pass of CoordinateDescentMinimizer::Minimize on the handle's current parameters, in place: set after set,
+ * every block is minimised over its own residual blocks by an LM with Ceres' default options, all blocks of a set
+ * at once on the device (inner_kernels.h).  *cost (may be NULL) receives 1/2 sum r^2 afterwards.  What
+ * cvx_calib_solve runs on every candidate while opt->inner_iterations is set and the passes still pay. */
+int cvx_calib_inner_pass(cvx_calib *h, double *cost);
 
 /* value CameraCalibration::refine returns: sqrt(total_cost / (2 n_obs)), calibration.cpp:463 */
 double cvx_calib_refine_return(double total_cost, int64_t n_obs_total);
