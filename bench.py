@@ -97,6 +97,7 @@ def cpu_baseline(views_per_camera, iters):
     d = cvx_amd.synth_calib(CAMERAS, views_per_camera, BOARD_W, BOARD_H, SEED)
     o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], CAMERAS, BOARD_W * BOARD_H)
     op = orc.options("refine")
+    op.inner_iterations = 0      # the same work as the GPU's timed steps
     op.max_iterations = iters
     op.function_tolerance = op.gradient_tolerance = op.parameter_tolerance = -1.0
     t = time.perf_counter()
@@ -312,6 +313,11 @@ def main():
             g.set_exchange(hook, rank, world, device_buffers=not a.host_exchange)
         opt = capi.options("refine")
         opt.function_tolerance = opt.gradient_tolerance = opt.parameter_tolerance = -1.0   # run every iteration asked
+        # The timed step is the LM iteration itself (linearise, Schur, solve, candidate).  Ceres' inner iterations
+        # (calibration.cpp:424) run on the candidates of the first iterations of a solve only -- they switch
+        # themselves off once a pass gains less than 1e-3 -- so they are not part of the steady-state step; what they
+        # cost is measured below (`inner_iterations` in the line: one pass, and the whole refine with and without).
+        opt.inner_iterations = 0
 
         def run(n_steps):
             done = 0
@@ -357,6 +363,10 @@ def main():
 
         # ---- one whole refine() with the reference's own options (calibration.cpp:420-428), start to convergence ----
         fo = capi.options("refine")
+        if world > 1:
+            fo.inner_iterations = 0      # a block's observations are spread over the ranks: not restated for shards
+        g.set_params(intr0, d["poses_init"], pts0)
+        g.solve(fo)                      # first use builds the inner-iteration ordering and lists (host work)
         g.set_params(intr0, d["poses_init"], pts0)
         fence()
         tf = time.perf_counter()
@@ -364,7 +374,26 @@ def main():
         torch.cuda.synchronize()
         trace("full refine done")
         full = {"iterations": fs.iterations, "termination": fs.termination, "ms_total": 1e3 * (time.perf_counter() - tf),
-                "initial_cost": fs.initial_cost, "final_cost": fs.final_cost}
+                "initial_cost": fs.initial_cost, "final_cost": fs.final_cost,
+                "inner_iterations": bool(fo.inner_iterations), "inner_iteration_steps": fs.num_inner_iteration_steps}
+        inner = None
+        if world == 1:
+            fo.inner_iterations = 0
+            g.set_params(intr0, d["poses_init"], pts0)
+            fence()
+            tf = time.perf_counter()
+            fs0 = g.solve(fo)
+            torch.cuda.synchronize()
+            ms0 = 1e3 * (time.perf_counter() - tf)
+            g.set_params(intr0, d["poses_init"], pts0)
+            fence()
+            tf = time.perf_counter()
+            c_pass = g.inner_pass()
+            ms_pass = 1e3 * (time.perf_counter() - tf)
+            inner = {"in_timed_steps": False, "one_pass_from_start_ms": ms_pass, "cost_before": fs.initial_cost,
+                     "cost_after_pass": c_pass, "refine_ms_with": full["ms_total"], "refine_iterations_with": fs.iterations,
+                     "refine_ms_without": ms0, "refine_iterations_without": fs0.iterations,
+                     "final_cost_with": fs.final_cost, "final_cost_without": fs0.final_cost}
 
         # ---- evaluation mode: residuals + Jacobian blocks materialised in HBM (k_eval), hipEvent-timed ----
         g.set_params(intr0, d["poses_init"], pts0)
@@ -502,6 +531,7 @@ def main():
                                   "frac": EVAL_BYTES_PER_OBS * N / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         out["full_refine_to_convergence"] = full
+        out["inner_iterations"] = inner
         out["handeye"] = handeye
         out["homography"] = homography
         out["tool_bundle_adjustment"] = toolba

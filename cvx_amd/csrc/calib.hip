@@ -1037,6 +1037,10 @@ extern "C" int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *c
 extern "C" int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *summary) {
     if (!h || !opt || !summary) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
+    if (opt->strategy != 1 && opt->inner_iterations && h->nranks > 1) {      // before any work, not at the first candidate
+        cvx::set_last_error("inner iterations need all observations of a block on one rank: clear cvx_lm_options.inner_iterations for view-sharded handles");
+        return CVX_ERR_UNSUPPORTED;
+    }
     CalibEvaluator ev(h);
     return cvx::lm_minimize(ev, *opt, *summary);
 }

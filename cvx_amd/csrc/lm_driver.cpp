@@ -235,6 +235,7 @@ extern "C" void cvx_lm_options_refine(cvx_lm_options *o) {
     o->max_iterations = 100;
     o->function_tolerance = 1e-10;
     o->gradient_tolerance = 1e-10;
+    o->inner_iterations = 1;         // calibration.cpp:424
 }
 
 extern "C" void cvx_lm_options_handeye(cvx_lm_options *o) {

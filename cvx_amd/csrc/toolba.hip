@@ -296,6 +296,7 @@ public:
 
 extern "C" void cvx_lm_options_toolba(cvx_lm_options *o) {     // hand_eye_registration.cpp:201-210
     cvx_lm_options_refine(o);
+    o->inner_iterations = 0;        // :205 sets use_inner_iterations too; restated for refine's problem only
     o->nonmonotonic = 0;
     o->function_tolerance = o->gradient_tolerance = o->parameter_tolerance = 1e-20;
 }

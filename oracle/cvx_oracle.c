@@ -478,6 +478,7 @@ void orc_lm_options_refine(orc_lm_options *o) {   /* calibration.cpp:420-428 */
     o->max_iterations = 100;
     o->function_tolerance = 1e-10;
     o->gradient_tolerance = 1e-10;
+    o->inner_iterations = 1;            /* calibration.cpp:424 */
 }
 void orc_lm_options_handeye(orc_lm_options *o) {  /* handeye.cpp:310-319 */
     lm_defaults(o);

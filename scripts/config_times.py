@@ -13,6 +13,7 @@ for name, (C_, VP, bw, bh, seed) in {"config1": (1, 20, 9, 6, 20260001), "config
     d = cvx_amd.synth_calib(C_, VP, bw, bh, seed)
     g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], C_, bw * bh)
     o = capi.options("refine")
+    o.inner_iterations = 0      # the LM iteration itself
     o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = -1.0
     o.max_iterations = 10
     for rep in range(3):

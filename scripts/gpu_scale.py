@@ -10,6 +10,7 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 t = time.time(); d = cvx_amd.synth_calib(C, VP, bw, bh, 20260004); print("synth %.2fs N=%d" % (time.time() - t, d['N']), flush=True)
 t = time.time(); g = cvx_amd.Calib(d['cam_of_view'], d['view_off'], d['point_id'], d['obs_x'], d['obs_y'], C, bw * bh); print("create %.2fs" % (time.time() - t), g.geometry(), flush=True)
 o = capi.options("refine"); o.max_iterations = K
+o.inner_iterations = 0      # the LM iteration itself
 o.function_tolerance = -1; o.gradient_tolerance = -1; o.parameter_tolerance = -1
 for rep in range(3):
     g.set_params(d['intr_init'], d['poses_init'], d['points_init'])

@@ -12,6 +12,7 @@ from cvx_amd import capi  # noqa: E402
 d = cvx_amd.synth_calib(8, 1250, 12, 9, 20260004)
 g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 8, 108)
 o = capi.options("refine")
+o.inner_iterations = 0      # the LM iteration itself
 o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = -1.0
 o.max_iterations = 3
 g.set_params(d["intr_init"], d["poses_init"], d["points_init"])

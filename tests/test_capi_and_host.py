@@ -185,6 +185,9 @@ def test_lm_driver_hands_back_the_lowest_cost_point():
     assert (r["final_cost"], r["at"], r["saved"], r["restored"], r["successful"]) == (40.0, 1, 0, 0, 2)
     b = rows["uphill_then_better"]   # a later, lower minimum makes the saved copy stale: not restored
     assert (b["final_cost"], b["at"], b["restored"]) == (30.0, 3, 0)
+    assert all(r["inner_calls"] == 0 for k, r in rows.items() if k != "inner_iterations")
+    i = rows["inner_iterations"]     # a pass that ends below the current cost makes the step; passes stop when they stop paying
+    assert (i["final_cost"], i["at"], i["successful"], i["inner_calls"], i["inner_steps"]) == (93.0, 3, 3, 3, 3)
 
 
 def test_schur_task_list_covers_every_block_and_every_stage_row_once():

@@ -16,6 +16,14 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+def sharded_options(capi):
+    """refine's options for view-sharded handles: inner iterations need a block's observations on one rank
+    (include/cvx_amd.h), so they are off here, on the sharded and on the single-rank side of every comparison"""
+    o = capi.options("refine")
+    o.inner_iterations = 0
+    return o
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -40,7 +48,7 @@ def _worker(rank, world, port, out):
     cb = capi.ALLREDUCE_FN(hook)
     g.set_exchange(cb, rank, world, device_buffers=False)
     g.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
-    s = g.solve(capi.options("refine"))
+    s = g.solve(sharded_options(capi))
     intr, poses, pts = g.get_params()
     res = {"it": s.iterations, "term": s.termination, "cost": s.final_cost, "trace": s.trace()["cost"].tolist(),
            "intr": intr.tolist(), "pts": pts.tolist(), "poses": poses.tolist(), "v0": int(first[rank])}
@@ -53,7 +61,7 @@ def _worker(rank, world, port, out):
     cb2 = bench.make_hook(torch, dist, capi)
     g2.set_exchange(cb2, rank, world, device_buffers=True)
     g2.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
-    s2 = g2.solve(capi.options("refine"))
+    s2 = g2.solve(sharded_options(capi))
     intr2, poses2, pts2 = g2.get_params()
     res["dev"] = {"it": s2.iterations, "term": s2.termination, "cost": s2.final_cost, "trace": s2.trace()["cost"].tolist(),
                   "intr": intr2.tolist(), "pts": pts2.tolist(), "poses": poses2.tolist()}
@@ -98,7 +106,7 @@ def test_two_rank_solve_equals_single_rank():
     d = cvx_amd.synth_calib(2, 9, 12, 9, 77, ragged=5)
     g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
     g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
-    s = g.solve(capi.options("refine"))
+    s = g.solve(sharded_options(capi))
     intr, poses, pts = g.get_params()
     r0, r1 = out[0], out[1]
     # both ranks hold bitwise identical shared parameters and costs (identical all-reduce results)
@@ -171,7 +179,7 @@ def _rccl_worker(rank, world, port, out):
     g = cvx_amd.Calib(sh["cam_of_view"], sh["view_off"], sh["point_id"], sh["obs_x"], sh["obs_y"], d["C"], d["P"], device=rank)
     g.set_exchange(C.cast(L.cvx_rccl_allreduce, C.c_void_p).value, rank, world, device_buffers=True, ctx=comm)
     g.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
-    s = g.solve(capi.options("refine"))
+    s = g.solve(sharded_options(capi))
     intr, poses, pts = g.get_params()
     out[rank] = {"it": s.iterations, "term": s.termination, "cost": s.final_cost, "trace": s.trace()["cost"].tolist(),
                  "intr": intr.tolist(), "pts": pts.tolist(), "poses": poses.tolist()}
@@ -194,7 +202,7 @@ def test_two_gpus_rccl_solve_equals_single_rank():
     d = cvx_amd.synth_calib(2, 9, 12, 9, 77, ragged=5)
     g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
     g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
-    s = g.solve(capi.options("refine"))
+    s = g.solve(sharded_options(capi))
     intr, poses, pts = g.get_params()
     g.close()
     r0, r1 = out[0], out[1]
