@@ -13,7 +13,8 @@
  *   - levmar 2.5 dlevmar_der control flow             modules/util/src/3rdparty/levmar/lm_core.c:60-423
  *   - Ceres Solver pieces the reference calls but does not vendor
  *     (AngleAxisRotatePoint, QuaternionParameterization, the Levenberg-Marquardt
- *     trust-region loop): restated from Ceres' published algorithm; version is
+ *     trust-region loop, inner iterations with their automatic ordering): restated
+ *     from Ceres' published algorithm; version is
  *     unpinned by the reference (libceres-dev, modules/calib/README.md:7).
  *
  * Parity pinning status:
@@ -23,7 +24,8 @@
  *   - Schur normal equations + Nielsen damping on the calibration functor:
  *     pinned against levmar (dense) driven by this file's callbacks
  *     (tests/golden/levmar_calib_trace.json).
- *   - The two cost functors themselves and the Ceres trust-region loop:
+ *   - The two cost functors themselves and the Ceres trust-region loop (inner
+ *     iterations included):
  *     PARITY UNPINNED -- the reference holds no golden vectors for them and
  *     Ceres/Eigen/OpenCV are absent from this image.  They are cross-checked
  *     three ways instead (analytic vs. forward-mode dual numbers vs. mpmath
