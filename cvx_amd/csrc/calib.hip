@@ -97,6 +97,8 @@ struct cvx_calib {
     std::vector<int> inner_types;    // per set: bit t set when the set holds blocks of type t (camera, point, pose)
     int *d_pt_off = nullptr, *d_pt_obs = nullptr, *d_blk_group = nullptr, *d_ib_flag = nullptr, *d_ib_active = nullptr;
     double *d_ib_H = nullptr, *d_ib_st = nullptr, *d_ib_xc = nullptr, *d_ib_cc = nullptr, *d_ib_slab = nullptr, *d_ib_out = nullptr;
+    double *d_ib_ptslab = nullptr;
+    int pt_slices = 1;               // workgroups per point block
     int *h_ib_active = nullptr;
     // exchange
     cvx_allreduce_fn xfn = nullptr;
@@ -120,7 +122,7 @@ cvx_calib::~cvx_calib() {
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_pt_off, d_pt_obs, d_blk_group,
-                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out};
+                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out, d_ib_ptslab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -358,6 +360,9 @@ int ensure_inner(cvx_calib *h) {
     st = dev_alloc(&h->d_ib_cc, (size_t)NB); if (st) return st;
     st = dev_alloc(&h->d_ib_slab, (size_t)std::max(1, h->n_groups) * cvxi::IB_STRIDE); if (st) return st;
     st = dev_alloc(&h->d_ib_out, 4); if (st) return st;
+    // a point's list is cut so that a workgroup of 256 lanes sees about two observations per lane
+    h->pt_slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, h->N / P / 512));
+    st = dev_alloc(&h->d_ib_ptslab, (size_t)P * h->pt_slices * cvxi::PT_SLOT); if (st) return st;
     CVX_HIP(hipMemsetAsync(h->d_ib_flag, 0, 4 * (size_t)NB * sizeof(int), s));
     CVX_HIP(hipMemsetAsync(h->d_ib_st, 0, (size_t)NB * cvxi::IB_STATE * sizeof(double), s));
     CVX_HIP(hipHostMalloc((void **)&h->h_ib_active, 4 * sizeof(int), hipHostMallocDefault));
@@ -384,6 +389,7 @@ int inner_pass(cvx_calib *h, int which) {
     a.intr = h->d_intr[which]; a.points = h->d_points[which]; a.poses = h->d_poses[which]; a.rt = h->d_rt[which];
     a.blk_group = h->d_blk_group; a.H = h->d_ib_H; a.st = h->d_ib_st; a.xc = h->d_ib_xc; a.cc = h->d_ib_cc;
     a.flag = h->d_ib_flag; a.cam_slab = h->d_ib_slab; a.active = h->d_ib_active;
+    a.pt_slab = h->d_ib_ptslab; a.pt_slices = h->pt_slices;
     a.C = h->C; a.P = h->P; a.V = h->V; a.ncf = h->ncf; a.fix_k3 = h->fix_k3; a.n_view_groups = h->n_groups;
     const dim3 per_block((NB + 63) / 64), t64(64);
     for (int set = 0; set < h->inner_sets; ++set) {
@@ -397,19 +403,17 @@ int inner_pass(cvx_calib *h, int which) {
         hipLaunchKernelGGL(cvxi::k_inner_reset, per_block, t64, 0, h->stream, a);
         for (int round = 0;; ++round) {
             if (round > 60) { cvx::set_last_error("inner iterations: a block did not terminate"); return CVX_ERR_NUMERIC; }
+            // blocks of the shared kinds: partial sums, then one fixed-order sum per block (ids 0 .. C + P - 1)
+            const dim3 pt_grid(h->P, h->pt_slices), shared_grid(h->C + h->P);
             if (poses) hipLaunchKernelGGL(cvxi::k_inner_pose<0>, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, a);
-            if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<0>, dim3(h->P), dim3(cvxi::IP_THREADS), 0, h->stream, a);
-            if (cams) {
-                hipLaunchKernelGGL(cvxi::k_inner_cam<0>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
-                hipLaunchKernelGGL(cvxi::k_inner_cam_sum<0>, dim3(h->C), t64, 0, h->stream, a);
-            }
+            if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<0>, pt_grid, dim3(cvxi::IP_THREADS), 0, h->stream, a);
+            if (cams) hipLaunchKernelGGL(cvxi::k_inner_cam<0>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
+            if (cams || pts) hipLaunchKernelGGL(cvxi::k_inner_sum<0>, shared_grid, dim3(cvxi::IS_THREADS), 0, h->stream, a);
             hipLaunchKernelGGL(cvxi::k_inner_solve, per_block, t64, 0, h->stream, a);
             if (poses) hipLaunchKernelGGL(cvxi::k_inner_pose<1>, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, a);
-            if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<1>, dim3(h->P), dim3(cvxi::IP_THREADS), 0, h->stream, a);
-            if (cams) {
-                hipLaunchKernelGGL(cvxi::k_inner_cam<1>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
-                hipLaunchKernelGGL(cvxi::k_inner_cam_sum<1>, dim3(h->C), t64, 0, h->stream, a);
-            }
+            if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<1>, pt_grid, dim3(cvxi::IP_THREADS), 0, h->stream, a);
+            if (cams) hipLaunchKernelGGL(cvxi::k_inner_cam<1>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
+            if (cams || pts) hipLaunchKernelGGL(cvxi::k_inner_sum<1>, shared_grid, dim3(cvxi::IS_THREADS), 0, h->stream, a);
             hipLaunchKernelGGL(cvxi::k_inner_decide, per_block, t64, 0, h->stream, a);
             CVX_HIP(hipGetLastError());
             CVX_HIP(hipMemcpyAsync(h->h_ib_active, h->d_ib_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -14,8 +14,9 @@
 // iteration:
 //   lin    normal equations H = J^T J, g = J^T r and the cost over the block's own observations
 //            pose block:   one wave per view (rotation table of the block's pose made in registers)
-//            point block:  one workgroup per point, over the point's observation list
+//            point block:  workgroups per point, over the point's observation list
 //            camera block: one workgroup per group of views of the camera (K2's groups), then a fixed-order sum
+//            (point blocks likewise when a point's list is long: several workgroups per point)
 //   solve  one thread per block: Jacobi scales (first round), gradient test, damped Cholesky solve with the
 //          invalid-step loop, parameter-tolerance test, candidate block
 //   cost   the candidate's cost over the same observations
@@ -34,6 +35,7 @@ using cvxk::RT_STRIDE;
 
 constexpr int IB_STRIDE = 56;    // per block: upper triangle of H (<= 45) | g at 45 (<= 9) | cost at 54
 constexpr int IB_G = 45, IB_COST = 54;
+constexpr int PT_SLOT = 16;      // per point slice: H (6) | g (3) | cost
 constexpr int IB_STATE = 16;     // per block: cost, radius, decrease factor, model change, first, pad, s2[9]
 enum { ST_COST = 0, ST_RADIUS, ST_DECREASE, ST_MODEL, ST_FIRST, ST_PAD, ST_S2 };
 enum { IB_CAM = 0, IB_POINT = 1, IB_POSE = 2 };
@@ -55,6 +57,8 @@ struct InnerArgs {
     double *H, *st, *xc, *cc;
     int *flag;
     double *cam_slab;                        // [view groups][IB_STRIDE]
+    double *pt_slab;                         // [points][pt_slices][PT_SLOT]
+    int pt_slices;                           // workgroups per point
     int *active;                             // blocks that go on after `decide`
     int C, P, V, ncf, fix_k3, n_view_groups;
     int cur;                                 // the set being minimised
@@ -82,6 +86,25 @@ __device__ __forceinline__ double group_sum(double v, double *sh) {
     return t;
 }
 
+// N sums over the workgroup at once, fixed order: on return thread t < N holds the t-th sum in acc[0].
+// sh: WAVES * N doubles
+template <int N, int WAVES>
+__device__ __forceinline__ void group_sum_n(double (&acc)[N], double *sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) sh[wave * N + i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double t = 0.0;
+        for (int w = 0; w < WAVES; ++w) t += sh[w * N + threadIdx.x];
+        acc[0] = t;
+    }
+}
+
 __device__ __forceinline__ bool block_runs(const InnerArgs &a, int id, int want) {
     return a.blk_group[id] == a.cur && a.flag[4 * id + FL_PHASE] == want;
 }
@@ -95,6 +118,7 @@ __global__ void __launch_bounds__(256) k_inner_pose(InnerArgs a) {
     if (v >= a.V) return;
     const int id = a.C + a.P + v;
     if (!block_runs(a, id, MODE == 0 ? PH_LIN : PH_CAND)) return;
+    // the block's rotation table, made by every lane for itself (by lane 0 through the wave's LDS row: 52 instead of 42 us)
     double rt[RT_STRIDE];
     cvxk::pose_table(MODE == 0 ? a.poses + 6 * (size_t)v : a.xc + 9 * (size_t)id, rt);
     const Intr in = load_intr(a.intr + 9 * a.cam_of_view[v]);
@@ -135,20 +159,24 @@ __global__ void __launch_bounds__(256) k_inner_pose(InnerArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// point blocks: one workgroup per point over its observation list
+// point blocks: pt_slices workgroups per point, each over its share of the point's observation list -> pt_slab;
+// k_inner_sum adds the slices in order
 // ---------------------------------------------------------------------------------------------
-constexpr int IP_THREADS = 512;
+constexpr int IP_THREADS = 256;
 template <int MODE>
 __global__ void __launch_bounds__(IP_THREADS) k_inner_point(InnerArgs a) {
-    __shared__ double sh[IP_THREADS / 64];
-    const int p = blockIdx.x, id = a.C + p;
+    constexpr int NA = MODE == 0 ? 10 : 1;
+    __shared__ double sh[(IP_THREADS / 64) * NA];
+    const int p = blockIdx.x, sl = blockIdx.y, id = a.C + p;
     if (!block_runs(a, id, MODE == 0 ? PH_LIN : PH_CAND)) return;        // the same for the whole workgroup
     const double *Xp = MODE == 0 ? a.points + 3 * p : a.xc + 9 * (size_t)id;
     const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
-    double acc[10];
+    double acc[NA];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = 0.0;
-    for (int k = a.pt_off[p] + threadIdx.x; k < a.pt_off[p + 1]; k += IP_THREADS) {
+    for (int i = 0; i < NA; ++i) acc[i] = 0.0;
+    const long long off = a.pt_off[p], len = a.pt_off[p + 1] - off;
+    const int k0 = (int)(off + len * sl / a.pt_slices), k1 = (int)(off + len * (sl + 1) / a.pt_slices);
+    for (int k = k0 + threadIdx.x; k < k1; k += IP_THREADS) {
         const int o = a.pt_obs[k], v = a.view_id[o];
         const Intr in = load_intr(a.intr + 9 * a.cam_of_view[v]);
         const double *rt = a.rt + (size_t)v * RT_STRIDE;
@@ -166,34 +194,25 @@ __global__ void __launch_bounds__(IP_THREADS) k_inner_point(InnerArgs a) {
         } else {
             cvxk::reproj_residual(in, rt, X0, X1, X2, a.obs_x[o], a.obs_y[o], r0, r1);
         }
-        acc[9] += r0 * r0 + r1 * r1;
+        acc[NA - 1] += r0 * r0 + r1 * r1;
     }
-    if (MODE == 0) {
-        double *H = a.H + (size_t)id * IB_STRIDE;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const double t = group_sum<IP_THREADS / 64>(acc[i], sh);
-            if (threadIdx.x == 0) H[i < 6 ? i : i < 9 ? IB_G + (i - 6) : IB_COST] = i == 9 ? 0.5 * t : t;
-        }
-    } else {
-        const double t = group_sum<IP_THREADS / 64>(acc[9], sh);
-        if (threadIdx.x == 0) a.cc[id] = 0.5 * t;
-    }
+    group_sum_n<NA, IP_THREADS / 64>(acc, sh);
+    if (threadIdx.x < NA) a.pt_slab[((size_t)p * a.pt_slices + sl) * PT_SLOT + (MODE == 0 ? threadIdx.x : 9)] = acc[0];
 }
 
 // ---------------------------------------------------------------------------------------------
-// camera blocks: one workgroup per view group (all of one camera) -> cam_slab; k_inner_cam_sum adds the groups
-// of a camera in list order.  H is the full 9 x 9 triangle; `solve` takes the free columns out of it.
+// camera blocks: one workgroup per view group (all of one camera) -> cam_slab; k_inner_sum adds the groups of a
+// camera in list order.  H is the full 9 x 9 triangle; `solve` takes the free columns out of it.
 // ---------------------------------------------------------------------------------------------
 constexpr int IC_THREADS = 256;
 template <int MODE>
 __global__ void __launch_bounds__(IC_THREADS) k_inner_cam(InnerArgs a) {
-    __shared__ double sh[IC_THREADS / 64];
+    constexpr int NA = MODE == 0 ? 55 : 1;
+    __shared__ double sh[(IC_THREADS / 64) * NA];
     const int g = blockIdx.x, v0 = a.grp_v0[g], v1 = a.grp_v0[g + 1];
     const int c = a.cam_of_view[v0];
     if (!block_runs(a, c, MODE == 0 ? PH_LIN : PH_CAND)) return;
     const Intr in = load_intr(MODE == 0 ? a.intr + 9 * c : a.xc + 9 * (size_t)c);
-    constexpr int NA = MODE == 0 ? 55 : 1;
     double acc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.0;
@@ -217,23 +236,36 @@ __global__ void __launch_bounds__(IC_THREADS) k_inner_cam(InnerArgs a) {
         }
         acc[NA - 1] += r0 * r0 + r1 * r1;
     }
-    double *out = a.cam_slab + (size_t)g * IB_STRIDE;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const double t = group_sum<IC_THREADS / 64>(acc[i], sh);
-        if (threadIdx.x == 0) out[MODE == 0 ? i : IB_COST] = t;
-    }
+    group_sum_n<NA, IC_THREADS / 64>(acc, sh);
+    if (threadIdx.x < NA) a.cam_slab[(size_t)g * IB_STRIDE + (MODE == 0 ? threadIdx.x : IB_COST)] = acc[0];
 }
 
+// the partial sums of a shared block, added in list order (four interleaved running sums, then those in order):
+// workgroup b < C: camera b over its view groups; workgroup C + p: point p over its slices
+constexpr int IS_THREADS = 256;
 template <int MODE>
-__global__ void __launch_bounds__(64) k_inner_cam_sum(InnerArgs a) {
-    const int c = blockIdx.x, k = threadIdx.x;
-    if (!block_runs(a, c, MODE == 0 ? PH_LIN : PH_CAND)) return;
-    if (MODE == 0 ? k > IB_COST : k != IB_COST) return;
+__global__ void __launch_bounds__(IS_THREADS) k_inner_sum(InnerArgs a) {
+    __shared__ double sh[4][64];
+    const int id = blockIdx.x, k = threadIdx.x & 63, j = threadIdx.x >> 6;
+    if (!block_runs(a, id, MODE == 0 ? PH_LIN : PH_CAND)) return;
+    const bool cam = id < a.C;
+    const int nval = cam ? 55 : 10, last = nval - 1;
     double s = 0.0;
-    for (int i = a.glist_off[c]; i < a.glist_off[c + 1]; ++i) s += a.cam_slab[(size_t)a.glist[i] * IB_STRIDE + k];
-    if (MODE == 0) a.H[(size_t)c * IB_STRIDE + k] = k == IB_COST ? 0.5 * s : s;
-    else a.cc[c] = 0.5 * s;
+    if (MODE == 0 ? k < nval : k == last) {
+        if (cam) {
+            for (int i = a.glist_off[id] + j; i < a.glist_off[id + 1]; i += 4) s += a.cam_slab[(size_t)a.glist[i] * IB_STRIDE + k];
+        } else {
+            const double *src = a.pt_slab + (size_t)(id - a.C) * a.pt_slices * PT_SLOT;
+            for (int i = j; i < a.pt_slices; i += 4) s += src[(size_t)i * PT_SLOT + k];
+        }
+    }
+    sh[j][k] = s;
+    __syncthreads();
+    if (j != 0 || (MODE == 0 ? k >= nval : k != last)) return;
+    const double t = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+    if (MODE == 1) { a.cc[id] = 0.5 * t; return; }
+    const int dst = cam ? k : (k < 6 ? k : k < 9 ? IB_G + (k - 6) : IB_COST);
+    a.H[(size_t)id * IB_STRIDE + dst] = k == last ? 0.5 * t : t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,52 +292,57 @@ __global__ void k_inner_reset(InnerArgs a) {
     st[ST_RADIUS] = 1e4; st[ST_DECREASE] = 2.0; st[ST_FIRST] = 1.0;
 }
 
-__global__ void __launch_bounds__(64) k_inner_solve(InnerArgs a) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id == 0) *a.active = 0;         // counted anew by this round's `decide`
-    if (id >= a.C + a.P + a.V || a.blk_group[id] != a.cur) return;
+// One LM iteration's linear part for a block of NF free columns in NG parameters (SKIP6: the intrinsics block with
+// k3 held -- free column k >= 6 is parameter k + 1).  Sizes are compile-time so that the small dense algebra stays in
+// registers; blocks of one type are contiguous in id, so a wave runs one instantiation (but for the two at a seam).
+template <int NF, int NG, bool SKIP6>
+__device__ __forceinline__ void ib_solve_block(const InnerArgs &a, int id, int phase, double *xp) {
+    auto col = [](int k) { return (SKIP6 && k >= 6) ? k + 1 : k; };
     int *fl = a.flag + 4 * id;
-    const int phase = fl[FL_PHASE];
-    if (phase != PH_LIN && phase != PH_RETRY) return;
-    const IbShape sh = ib_shape(a, id);
-    const int nf = sh.nf, ng = sh.ng;
     const double *H = a.H + (size_t)id * IB_STRIDE;
     double *st = a.st + (size_t)id * IB_STATE;
-    double g[9], diag[9], s2[9];
-    for (int i = 0; i < nf; ++i) {
-        const int ci = ib_col(a, sh.type, i);
-        g[i] = H[IB_G + ci];
-        diag[i] = H[tri(ng, ci, ci)];
+    double g[NF], diag[NF], s2[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        g[i] = H[IB_G + col(i)];
+        diag[i] = H[tri(NG, col(i), col(i))];
     }
     if (phase == PH_LIN) {
         if (st[ST_FIRST] != 0.0) {
-            for (int i = 0; i < nf; ++i) { const double s = 1.0 / (1.0 + sqrt(diag[i])); st[ST_S2 + i] = s * s; }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) { const double s = 1.0 / (1.0 + sqrt(diag[i])); st[ST_S2 + i] = s * s; }
             st[ST_FIRST] = 0.0;
         }
         st[ST_COST] = H[IB_COST];
         double gmax = 0.0;
-        for (int i = 0; i < nf; ++i) gmax = fmax(gmax, fabs(g[i]));
+#pragma unroll
+        for (int i = 0; i < NF; ++i) gmax = fmax(gmax, fabs(g[i]));
         if (gmax <= 1e-10) { fl[FL_TERM] = 1; fl[FL_PHASE] = PH_DONE; return; }
     }
-    for (int i = 0; i < nf; ++i) s2[i] = st[ST_S2 + i];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) s2[i] = st[ST_S2 + i];
     double radius = st[ST_RADIUS];
     int iters = fl[FL_ITERS], invalid = fl[FL_INVALID];
-    double x[9];
-    for (int i = 0; i < ng; ++i) x[i] = sh.x[i];
+    double x[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) x[i] = xp[i];
     for (;;) {
         if (iters >= 50) { fl[FL_TERM] = 4; fl[FL_PHASE] = PH_DONE; break; }
         ++iters;
-        double D[9], L[45], d[9];
-        for (int i = 0; i < nf; ++i) {
+        double D[NF], L[NF * (NF + 1) / 2], d[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
             const double t = fmin(fmax(s2[i] * diag[i], 1e-6), 1e32);
             D[i] = t / (s2[i] * radius);
         }
         // Cholesky of H_free + D (lower triangle, row-major packed: L[i(i+1)/2 + j])
         bool ok = true;
-        for (int i = 0; i < nf; ++i)
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
             for (int j = 0; j <= i; ++j) {
-                const int ci = ib_col(a, sh.type, i), cj = ib_col(a, sh.type, j);
-                double t = H[tri(ng, cj, ci)] + (i == j ? D[i] : 0.0);
+                double t = H[tri(NG, col(j), col(i))] + (i == j ? D[i] : 0.0);
+#pragma unroll
                 for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
                 if (i == j) {
                     if (!(t > 0.0) || !(t < 1.7e308)) { ok = false; t = 1.0; }
@@ -314,18 +351,23 @@ __global__ void __launch_bounds__(64) k_inner_solve(InnerArgs a) {
                     L[i * (i + 1) / 2 + j] = t / L[j * (j + 1) / 2 + j];
                 }
             }
-        for (int i = 0; i < nf; ++i) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
             double t = -g[i];
+#pragma unroll
             for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * d[k];
             d[i] = t / L[i * (i + 1) / 2 + i];
         }
-        for (int i = nf - 1; i >= 0; --i) {
+#pragma unroll
+        for (int i = NF - 1; i >= 0; --i) {
             double t = d[i];
-            for (int k = i + 1; k < nf; ++k) t -= L[k * (k + 1) / 2 + i] * d[k];
+#pragma unroll
+            for (int k = i + 1; k < NF; ++k) t -= L[k * (k + 1) / 2 + i] * d[k];
             d[i] = t / L[i * (i + 1) / 2 + i];
         }
         double mc = 0.0;
-        for (int i = 0; i < nf; ++i) mc += d[i] * (D[i] * d[i] - g[i]);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) mc += d[i] * (D[i] * d[i] - g[i]);
         mc *= 0.5;
         if (!ok || !(mc > 0.0)) {
             if (++invalid >= 5) { fl[FL_TERM] = 6; fl[FL_PHASE] = PH_DONE; break; }
@@ -333,20 +375,37 @@ __global__ void __launch_bounds__(64) k_inner_solve(InnerArgs a) {
             continue;
         }
         invalid = 0;
-        double xc[9];
-        for (int i = 0; i < ng; ++i) xc[i] = x[i];
-        for (int i = 0; i < nf; ++i) xc[ib_col(a, sh.type, i)] += d[i];
+        double xc[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) xc[i] = x[i];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) xc[col(i)] += d[i];
         double sn = 0.0, xn = 0.0;
-        for (int i = 0; i < ng; ++i) { const double e = x[i] - xc[i]; sn += e * e; xn += x[i] * x[i]; }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) { const double e = x[i] - xc[i]; sn += e * e; xn += x[i] * x[i]; }
         sn = sqrt(sn); xn = sqrt(xn);
         if (sn <= 1e-8 * (xn + 1e-8)) { fl[FL_TERM] = 2; fl[FL_PHASE] = PH_DONE; break; }
-        for (int i = 0; i < ng; ++i) a.xc[9 * (size_t)id + i] = xc[i];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) a.xc[9 * (size_t)id + i] = xc[i];
         st[ST_MODEL] = mc;
         fl[FL_PHASE] = PH_CAND;
         break;
     }
     st[ST_RADIUS] = radius;
     fl[FL_ITERS] = iters; fl[FL_INVALID] = invalid;
+}
+
+__global__ void __launch_bounds__(64) k_inner_solve(InnerArgs a) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id == 0) *a.active = 0;         // counted anew by this round's `decide`
+    if (id >= a.C + a.P + a.V || a.blk_group[id] != a.cur) return;
+    const int phase = a.flag[4 * id + FL_PHASE];
+    if (phase != PH_LIN && phase != PH_RETRY) return;
+    const IbShape sh = ib_shape(a, id);
+    if (sh.type == IB_POSE) ib_solve_block<6, 6, false>(a, id, phase, sh.x);
+    else if (sh.type == IB_POINT) ib_solve_block<3, 3, false>(a, id, phase, sh.x);
+    else if (a.ncf == 8) ib_solve_block<8, 9, true>(a, id, phase, sh.x);
+    else ib_solve_block<9, 9, false>(a, id, phase, sh.x);
 }
 
 __global__ void __launch_bounds__(64) k_inner_decide(InnerArgs a) {
