@@ -364,7 +364,7 @@ def main():
         # ---- one whole refine() with the reference's own options (calibration.cpp:420-428), start to convergence ----
         fo = capi.options("refine")
         if world > 1:
-            fo.inner_iterations = 0      # a block's observations are spread over the ranks: not restated for shards
+            fo.inner_iterations = 0      # the scaling runs measure the LM iteration; the passes on shards are covered by tests/test_gpu_multirank.py
         g.set_params(intr0, d["poses_init"], pts0)
         g.solve(fo)                      # first use builds the inner-iteration ordering and lists (host work)
         g.set_params(intr0, d["poses_init"], pts0)

@@ -95,11 +95,13 @@ struct cvx_calib {
     bool inner_ready = false;
     int inner_sets = 0;
     std::vector<int> inner_types;    // per set: bit t set when the set holds blocks of type t (camera, point, pose)
-    int *d_pt_off = nullptr, *d_pt_obs = nullptr, *d_blk_group = nullptr, *d_ib_flag = nullptr, *d_ib_active = nullptr;
+    int *d_pt_off = nullptr, *d_pt_obs = nullptr, *d_blk_group = nullptr, *d_ib_flag = nullptr;
+    double *d_ib_active = nullptr, *d_ib_X = nullptr;   // blocks that go on; exchange buffer of the shared blocks' sums
+    std::vector<double> x_stage;     // host staging of an exchange over a host-buffer hook
     double *d_ib_H = nullptr, *d_ib_st = nullptr, *d_ib_xc = nullptr, *d_ib_cc = nullptr, *d_ib_slab = nullptr, *d_ib_out = nullptr;
     double *d_ib_ptslab = nullptr;
     int pt_slices = 1;               // workgroups per point block
-    int *h_ib_active = nullptr;
+    double *h_ib_active = nullptr;   // pinned: [0] blocks that go on, [1..2] step norm parts
     // exchange
     cvx_allreduce_fn xfn = nullptr;
     void *xctx = nullptr;
@@ -122,7 +124,7 @@ cvx_calib::~cvx_calib() {
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_pt_off, d_pt_obs, d_blk_group,
-                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out, d_ib_ptslab};
+                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out, d_ib_ptslab, d_ib_X};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -327,20 +329,100 @@ int cost_of(cvx_calib *h, int which, double *cost) {
     return CVX_OK;
 }
 
-// ---- inner iterations (calibration.cpp:424): ordering, per-point observation lists and block state, on first use
+// sum of `count` doubles of a device buffer over the ranks, in place, through the hook in the mode it was registered for
+int exchange_sum(cvx_calib *h, double *d, size_t count) {
+    if (h->nranks <= 1 || count == 0) return CVX_OK;
+    if (h->xdev) return h->xfn(h->xctx, d, count, 1, (void *)h->stream) ? CVX_ERR_EXCHANGE : CVX_OK;
+    h->x_stage.resize(count);
+    CVX_HIP(hipMemcpyAsync(h->x_stage.data(), d, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    if (h->xfn(h->xctx, h->x_stage.data(), count, 0, nullptr)) return CVX_ERR_EXCHANGE;
+    CVX_HIP(hipMemcpyAsync(d, h->x_stage.data(), count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+// the same for values that live on the host
+int exchange_sum_host(cvx_calib *h, std::vector<double> &v) {
+    if (h->nranks <= 1 || v.empty()) return CVX_OK;
+    if (!h->xdev) return h->xfn(h->xctx, v.data(), v.size(), 0, nullptr) ? CVX_ERR_EXCHANGE : CVX_OK;
+    double *d = nullptr;
+    int st = dev_alloc(&d, v.size());
+    if (st) return st;
+    hipError_t e = hipMemcpyAsync(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    int rc = 0;
+    if (e == hipSuccess) rc = h->xfn(h->xctx, d, v.size(), 1, (void *)h->stream);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(v.data(), d, v.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (rc) return CVX_ERR_EXCHANGE;
+    CVX_HIP(e);
+    return CVX_OK;
+}
+
+void free_inner(cvx_calib *h) {
+    void *ptrs[] = {h->d_pt_off, h->d_pt_obs, h->d_blk_group, h->d_ib_flag, h->d_ib_active, h->d_ib_H, h->d_ib_st, h->d_ib_xc,
+                    h->d_ib_cc, h->d_ib_slab, h->d_ib_out, h->d_ib_ptslab, h->d_ib_X};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    h->d_pt_off = h->d_pt_obs = h->d_blk_group = h->d_ib_flag = nullptr;
+    h->d_ib_active = h->d_ib_H = h->d_ib_st = h->d_ib_xc = h->d_ib_cc = h->d_ib_slab = h->d_ib_out = h->d_ib_ptslab = h->d_ib_X = nullptr;
+    h->inner_ready = false;
+}
+
+// ---- inner iterations (calibration.cpp:424): ordering, per-point observation lists and block state, on first use.
+// View-sharded runs (a collective: every rank gets here at its first pass): the ordering is a function of the WHOLE
+// problem's graph, so the ranks first put their views' structure together -- camera, marker count and point ids of
+// every view, each rank's part at its offset of a zero buffer, one all-reduce -- and every rank orders the whole
+// problem; rank by rank the views follow each other as in the unsharded problem, so the sets are the same as there.
 int ensure_inner(cvx_calib *h) {
     if (h->inner_ready) return CVX_OK;
+    free_inner(h);
     const int C = h->C, P = h->P, V = h->V, NB = C + P + V;
     std::vector<int> point_id((size_t)h->N);
     if (h->N) CVX_HIP(hipMemcpyAsync(point_id.data(), h->d_point_id, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
     std::vector<int> group(NB);
-    int st = cvx_calib_inner_ordering(C, V, P, h->h_cam_of_view.data(), h->h_view_off.data(), point_id.data(), h->fix_intr,
+    int st;
+    if (h->nranks > 1) {
+        const int R = h->nranks;
+        std::vector<double> cnt(2 * (size_t)R, 0.0);
+        cnt[2 * h->rank] = V; cnt[2 * h->rank + 1] = (double)h->N;
+        st = exchange_sum_host(h, cnt);
+        if (st) return st;
+        int64_t Vt = 0, Nt = 0, v0 = 0, o0 = 0;
+        for (int r = 0; r < R; ++r) {
+            if (r == h->rank) { v0 = Vt; o0 = Nt; }
+            Vt += (int64_t)cnt[2 * r]; Nt += (int64_t)cnt[2 * r + 1];
+        }
+        if (Vt > 0x7fffffff || Nt > 0x7fffffff) return CVX_ERR_UNSUPPORTED;
+        std::vector<double> all((size_t)(2 * Vt + Nt), 0.0);        // cameras | marker counts | point ids
+        for (int v = 0; v < V; ++v) {
+            all[(size_t)(v0 + v)] = h->h_cam_of_view[v];
+            all[(size_t)(Vt + v0 + v)] = h->h_view_off[v + 1] - h->h_view_off[v];
+        }
+        for (int64_t o = 0; o < h->N; ++o) all[(size_t)(2 * Vt + o0 + o)] = point_id[o];
+        st = exchange_sum_host(h, all);
+        if (st) return st;
+        std::vector<int> gcam((size_t)Vt), goff((size_t)Vt + 1, 0), gpid((size_t)Nt), ggroup((size_t)(C + P + Vt));
+        for (int64_t v = 0; v < Vt; ++v) { gcam[v] = (int)all[(size_t)v]; goff[v + 1] = goff[v] + (int)all[(size_t)(Vt + v)]; }
+        for (int64_t o = 0; o < Nt; ++o) gpid[o] = (int)all[(size_t)(2 * Vt + o)];
+        st = cvx_calib_inner_ordering(C, (int)Vt, P, gcam.data(), goff.data(), gpid.data(), h->fix_intr, h->fix_pts,
+                                      ggroup.data(), &h->inner_sets);
+        if (st) return st;
+        // what a set holds is decided on the whole problem: every rank then runs the same kernels and exchanges
+        h->inner_types.assign(h->inner_sets, 0);
+        for (int64_t i = 0; i < C + P + Vt; ++i)
+            if (ggroup[i] >= 0) h->inner_types[ggroup[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
+        for (int i = 0; i < C + P; ++i) group[i] = ggroup[i];
+        for (int v = 0; v < V; ++v) group[C + P + v] = ggroup[(size_t)(C + P + v0 + v)];
+    } else {
+        st = cvx_calib_inner_ordering(C, V, P, h->h_cam_of_view.data(), h->h_view_off.data(), point_id.data(), h->fix_intr,
                                       h->fix_pts, group.data(), &h->inner_sets);
-    if (st) return st;
-    h->inner_types.assign(h->inner_sets, 0);
-    for (int i = 0; i < NB; ++i)
-        if (group[i] >= 0) h->inner_types[group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
+        if (st) return st;
+        h->inner_types.assign(h->inner_sets, 0);
+        for (int i = 0; i < NB; ++i)
+            if (group[i] >= 0) h->inner_types[group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
+    }
     std::vector<int> pt_off((size_t)P + 1, 0), pt_obs((size_t)h->N);
     for (int64_t o = 0; o < h->N; ++o) pt_off[point_id[o] + 1]++;
     for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
@@ -360,12 +442,13 @@ int ensure_inner(cvx_calib *h) {
     st = dev_alloc(&h->d_ib_cc, (size_t)NB); if (st) return st;
     st = dev_alloc(&h->d_ib_slab, (size_t)std::max(1, h->n_groups) * cvxi::IB_STRIDE); if (st) return st;
     st = dev_alloc(&h->d_ib_out, 4); if (st) return st;
+    st = dev_alloc(&h->d_ib_X, (size_t)(C + P) * cvxi::IB_STRIDE); if (st) return st;
     // a point's list is cut so that a workgroup of 256 lanes sees about two observations per lane
     h->pt_slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, h->N / P / 512));
     st = dev_alloc(&h->d_ib_ptslab, (size_t)P * h->pt_slices * cvxi::PT_SLOT); if (st) return st;
     CVX_HIP(hipMemsetAsync(h->d_ib_flag, 0, 4 * (size_t)NB * sizeof(int), s));
     CVX_HIP(hipMemsetAsync(h->d_ib_st, 0, (size_t)NB * cvxi::IB_STATE * sizeof(double), s));
-    CVX_HIP(hipHostMalloc((void **)&h->h_ib_active, 4 * sizeof(int), hipHostMallocDefault));
+    if (!h->h_ib_active) CVX_HIP(hipHostMalloc((void **)&h->h_ib_active, 4 * sizeof(double), hipHostMallocDefault));
     CVX_HIP(hipStreamSynchronize(s));       // the uploads read host vectors that end here
     h->inner_ready = true;
     return CVX_OK;
@@ -373,15 +456,15 @@ int ensure_inner(cvx_calib *h) {
 
 // One pass of CoordinateDescentMinimizer::Minimize on parameter buffer `which`, in place: set after set, every
 // block of the set advances one LM iteration per round until none goes on (at most 50 iterations each, plus the
-// rounds a block spends on invalid steps: bounded by the round limit below)
+// rounds a block spends on invalid steps: bounded by the round limit below).
+// View-sharded runs: pose blocks are a rank's own; a camera's or a point's observations are spread over the ranks,
+// so in a set that holds such blocks every round all-reduces their sums (H | g | cost rows, then the candidates'
+// costs) and the count of blocks that go on -- the ranks then take the same decisions and leave the set together.
 int inner_pass(cvx_calib *h, int which) {
-    if (h->nranks > 1) {
-        cvx::set_last_error("inner iterations need all observations of a block on one rank");
-        return CVX_ERR_UNSUPPORTED;
-    }
     int st = ensure_inner(h);
     if (st) return st;
-    const int NB = h->C + h->P + h->V;
+    const int NB = h->C + h->P + h->V, nsh = h->C + h->P;
+    const bool sharded = h->nranks > 1 && h->xfn;
     cvxi::InnerArgs a;
     a.view_off = h->d_view_off; a.cam_of_view = h->d_cam_of_view; a.point_id = h->d_point_id; a.view_id = h->d_view_id;
     a.obs_x = h->d_obs_x; a.obs_y = h->d_obs_y; a.pt_off = h->d_pt_off; a.pt_obs = h->d_pt_obs;
@@ -394,8 +477,9 @@ int inner_pass(cvx_calib *h, int which) {
     const dim3 per_block((NB + 63) / 64), t64(64);
     for (int set = 0; set < h->inner_sets; ++set) {
         const int types = h->inner_types[set];
-        const bool cams = types & (1 << cvxi::IB_CAM), pts = types & (1 << cvxi::IB_POINT), poses = types & (1 << cvxi::IB_POSE);
-        if (cams || pts) {                  // they read the rotation tables of the point being improved
+        const bool cams = types & (1 << cvxi::IB_CAM), pts = types & (1 << cvxi::IB_POINT), poses = (types & (1 << cvxi::IB_POSE)) && h->V > 0;
+        const bool shared = cams || pts;
+        if (shared) {                       // they read the rotation tables of the point being improved
             st = launch_pose_prepare(h, which);
             if (st) return st;
         }
@@ -404,21 +488,37 @@ int inner_pass(cvx_calib *h, int which) {
         for (int round = 0;; ++round) {
             if (round > 60) { cvx::set_last_error("inner iterations: a block did not terminate"); return CVX_ERR_NUMERIC; }
             // blocks of the shared kinds: partial sums, then one fixed-order sum per block (ids 0 .. C + P - 1)
-            const dim3 pt_grid(h->P, h->pt_slices), shared_grid(h->C + h->P);
+            const dim3 pt_grid(h->P, h->pt_slices), shared_grid(nsh);
             if (poses) hipLaunchKernelGGL(cvxi::k_inner_pose<0>, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, a);
             if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<0>, pt_grid, dim3(cvxi::IP_THREADS), 0, h->stream, a);
-            if (cams) hipLaunchKernelGGL(cvxi::k_inner_cam<0>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
-            if (cams || pts) hipLaunchKernelGGL(cvxi::k_inner_sum<0>, shared_grid, dim3(cvxi::IS_THREADS), 0, h->stream, a);
+            if (cams && h->n_groups) hipLaunchKernelGGL(cvxi::k_inner_cam<0>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
+            if (shared) hipLaunchKernelGGL(cvxi::k_inner_sum<0>, shared_grid, dim3(cvxi::IS_THREADS), 0, h->stream, a);
+            if (shared && sharded) {
+                hipLaunchKernelGGL((cvxi::k_inner_xchg<0, 0>), shared_grid, t64, 0, h->stream, a, h->d_ib_X);
+                st = exchange_sum(h, h->d_ib_X, (size_t)nsh * cvxi::IB_STRIDE);
+                if (st) return st;
+                hipLaunchKernelGGL((cvxi::k_inner_xchg<0, 1>), shared_grid, t64, 0, h->stream, a, h->d_ib_X);
+            }
             hipLaunchKernelGGL(cvxi::k_inner_solve, per_block, t64, 0, h->stream, a);
             if (poses) hipLaunchKernelGGL(cvxi::k_inner_pose<1>, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, a);
             if (pts) hipLaunchKernelGGL(cvxi::k_inner_point<1>, pt_grid, dim3(cvxi::IP_THREADS), 0, h->stream, a);
-            if (cams) hipLaunchKernelGGL(cvxi::k_inner_cam<1>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
-            if (cams || pts) hipLaunchKernelGGL(cvxi::k_inner_sum<1>, shared_grid, dim3(cvxi::IS_THREADS), 0, h->stream, a);
+            if (cams && h->n_groups) hipLaunchKernelGGL(cvxi::k_inner_cam<1>, dim3(h->n_groups), dim3(cvxi::IC_THREADS), 0, h->stream, a);
+            if (shared) hipLaunchKernelGGL(cvxi::k_inner_sum<1>, shared_grid, dim3(cvxi::IS_THREADS), 0, h->stream, a);
+            if (shared && sharded) {
+                hipLaunchKernelGGL((cvxi::k_inner_xchg<1, 0>), shared_grid, t64, 0, h->stream, a, h->d_ib_X);
+                st = exchange_sum(h, h->d_ib_X, (size_t)nsh);
+                if (st) return st;
+                hipLaunchKernelGGL((cvxi::k_inner_xchg<1, 1>), shared_grid, t64, 0, h->stream, a, h->d_ib_X);
+            }
             hipLaunchKernelGGL(cvxi::k_inner_decide, per_block, t64, 0, h->stream, a);
             CVX_HIP(hipGetLastError());
-            CVX_HIP(hipMemcpyAsync(h->h_ib_active, h->d_ib_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            if (shared && sharded) {        // leave the set together (a set of pose blocks only has nothing to agree on)
+                st = exchange_sum(h, h->d_ib_active, 1);
+                if (st) return st;
+            }
+            CVX_HIP(hipMemcpyAsync(h->h_ib_active, h->d_ib_active, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             CVX_HIP(hipStreamSynchronize(h->stream));
-            if (h->h_ib_active[0] == 0) break;
+            if (h->h_ib_active[0] == 0.0) break;
         }
         if (poses) h->rt_valid[which] = false;
     }
@@ -517,10 +617,16 @@ public:
                            9LL * h->C, h->d_points[h->cur], h->d_points[nxt], 3LL * h->P, h->d_poses[h->cur], h->d_poses[nxt],
                            6LL * h->V, h->d_ib_out);
         CVX_HIP(hipGetLastError());
-        CVX_HIP(hipMemcpyAsync(h->h_ib_active + 2, h->d_ib_out, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CVX_HIP(hipMemcpyAsync(h->h_ib_active + 1, h->d_ib_out, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         st = cost_of(h, nxt, cost);         // synchronises the stream
         if (st) return st;
-        std::memcpy(step_norm2, h->h_ib_active + 2, sizeof(double));
+        if (h->nranks > 1 && h->xfn) {      // the cost and the poses' part of the norm are this rank's share
+            std::vector<double> v = {*cost, h->h_ib_active[2]};
+            st = exchange_sum_host(h, v);
+            if (st) return st;
+            *cost = v[0]; h->h_ib_active[2] = v[1];
+        }
+        *step_norm2 = h->h_ib_active[1] + h->h_ib_active[2];
         return CVX_OK;
     }
 
@@ -1032,6 +1138,7 @@ extern "C" int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *c
     if (!h || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
     h->xfn = fn; h->xctx = ctx; h->rank = rank; h->nranks = nranks; h->xdev = device_buffers ? 1 : 0;
+    h->inner_ready = false;     // the inner iterations' ordering is a function of the whole problem
     int st = alloc_exchange(h);
     if (st) return st;
     CVX_HIP(hipStreamSynchronize(h->stream));
@@ -1041,10 +1148,6 @@ extern "C" int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *c
 extern "C" int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *summary) {
     if (!h || !opt || !summary) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
-    if (opt->strategy != 1 && opt->inner_iterations && h->nranks > 1) {      // before any work, not at the first candidate
-        cvx::set_last_error("inner iterations need all observations of a block on one rank: clear cvx_lm_options.inner_iterations for view-sharded handles");
-        return CVX_ERR_UNSUPPORTED;
-    }
     CalibEvaluator ev(h);
     return cvx::lm_minimize(ev, *opt, *summary);
 }

@@ -59,7 +59,7 @@ struct InnerArgs {
     double *cam_slab;                        // [view groups][IB_STRIDE]
     double *pt_slab;                         // [points][pt_slices][PT_SLOT]
     int pt_slices;                           // workgroups per point
-    int *active;                             // blocks that go on after `decide`
+    double *active;                          // number of blocks that go on after `decide` (a double: it is all-reduced)
     int C, P, V, ncf, fix_k3, n_view_groups;
     int cur;                                 // the set being minimised
 };
@@ -285,7 +285,7 @@ __device__ __forceinline__ int ib_col(const InnerArgs &a, int type, int k) { ret
 
 __global__ void k_inner_reset(InnerArgs a) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id == 0) *a.active = 0;
+    if (id == 0) *a.active = 0.0;
     if (id >= a.C + a.P + a.V || a.blk_group[id] != a.cur) return;
     a.flag[4 * id + FL_PHASE] = PH_LIN; a.flag[4 * id + FL_ITERS] = 0; a.flag[4 * id + FL_INVALID] = 0; a.flag[4 * id + FL_TERM] = 0;
     double *st = a.st + (size_t)id * IB_STATE;
@@ -397,7 +397,7 @@ __device__ __forceinline__ void ib_solve_block(const InnerArgs &a, int id, int p
 
 __global__ void __launch_bounds__(64) k_inner_solve(InnerArgs a) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id == 0) *a.active = 0;         // counted anew by this round's `decide`
+    if (id == 0) *a.active = 0.0;       // counted anew by this round's `decide`
     if (id >= a.C + a.P + a.V || a.blk_group[id] != a.cur) return;
     const int phase = a.flag[4 * id + FL_PHASE];
     if (phase != PH_LIN && phase != PH_RETRY) return;
@@ -433,10 +433,30 @@ __global__ void __launch_bounds__(64) k_inner_decide(InnerArgs a) {
         if (radius < 1e-32) { fl[FL_TERM] = 5; fl[FL_PHASE] = PH_DONE; return; }
         fl[FL_PHASE] = PH_RETRY;
     }
-    atomicAdd(a.active, 1);
+    atomicAdd(a.active, 1.0);           // integers in a double: exact in any order
 }
 
-// |x - y|^2 over the three parameter arrays (the step norm of the outer iteration after the pass), one workgroup
+// View-sharded runs: a shared block's sums are partial on every rank.  DIR 0 lays the rows of the running blocks
+// (zeros for all others) into the exchange buffer X, DIR 1 takes the all-reduced rows back.  The LM state of a
+// shared block is replicated -- every rank takes the same decisions from the same sums -- so "running" is the same
+// everywhere.  MODE 0: rows of H | g | cost; MODE 1: candidate costs.
+template <int MODE, int DIR>
+__global__ void __launch_bounds__(64) k_inner_xchg(InnerArgs a, double *X) {
+    const int id = blockIdx.x, k = threadIdx.x;
+    const bool run = block_runs(a, id, MODE == 0 ? PH_LIN : PH_CAND);
+    if (MODE == 0) {
+        if (k >= IB_STRIDE) return;
+        const size_t e = (size_t)id * IB_STRIDE + k;
+        if (DIR == 0) X[e] = run ? a.H[e] : 0.0;
+        else if (run) a.H[e] = X[e];
+    } else {
+        if (k != 0) return;
+        if (DIR == 0) X[id] = run ? a.cc[id] : 0.0;
+        else if (run) a.cc[id] = X[id];
+    }
+}
+
+// |x - y|^2 over the parameter arrays (the step norm of the outer iteration after the pass), one workgroup
 __global__ void __launch_bounds__(1024) k_inner_step_norm(const double *i0, const double *i1, long long ni, const double *p0,
                                                           const double *p1, long long np, const double *v0, const double *v1,
                                                           long long nv, double *out) {
@@ -444,9 +464,11 @@ __global__ void __launch_bounds__(1024) k_inner_step_norm(const double *i0, cons
     double s = 0.0;
     for (long long i = threadIdx.x; i < ni; i += 1024) { const double e = i0[i] - i1[i]; s += e * e; }
     for (long long i = threadIdx.x; i < np; i += 1024) { const double e = p0[i] - p1[i]; s += e * e; }
+    const double shared = group_sum<16>(s, sh);
+    s = 0.0;
     for (long long i = threadIdx.x; i < nv; i += 1024) { const double e = v0[i] - v1[i]; s += e * e; }
-    const double t = group_sum<16>(s, sh);
-    if (threadIdx.x == 0) out[0] = t;
+    const double poses = group_sum<16>(s, sh);
+    if (threadIdx.x == 0) { out[0] = shared; out[1] = poses; }      // shared blocks (replicated) | this rank's poses
 }
 
 }  // namespace cvxi

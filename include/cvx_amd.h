@@ -61,8 +61,9 @@ typedef struct {
     int nonmonotonic;
     int max_consecutive_nonmonotonic_steps;
     double tau, eps1, eps2, eps3;
-    int inner_iterations;               /* Solver::Options::use_inner_iterations (calibration.cpp:424); strategy 0,
-                                           calibration handles only: other solves return CVX_ERR_UNSUPPORTED with it */
+    int inner_iterations;               /* Solver::Options::use_inner_iterations (calibration.cpp:424); strategy 0 of
+                                           cvx_calib_solve only: the other solves return CVX_ERR_UNSUPPORTED with it,
+                                           strategy 1 ignores it */
     double inner_iteration_tolerance;   /* Ceres default 1e-3 */
 } cvx_lm_options;
 
@@ -86,9 +87,8 @@ typedef struct {
  * options (the reference holds no vectors for this loop, parity unpinned): linear solves are
  * exact (the reference's ITERATIVE_SCHUR + SCHUR_JACOBI conjugate gradients are inexact).  Non-monotonic steps are
  * restated, including that the solve hands back the lowest-cost point it visited; inner iterations are, with the
- * ordering Ceres builds when none is given (cvx_calib_inner_ordering).  Inner iterations need all observations of
- * a block on one rank: a view-sharded handle (cvx_calib_set_exchange with nranks > 1) returns CVX_ERR_UNSUPPORTED
- * for them -- clear the flag there. */
+ * ordering Ceres builds when none is given (cvx_calib_inner_ordering); on view-sharded handles too (the ordering
+ * is then made from the whole problem's structure, gathered through the exchange hook at the first pass). */
 void cvx_lm_options_refine(cvx_lm_options *o);
 void cvx_lm_options_handeye(cvx_lm_options *o);  /* handeye.cpp:310-319 */
 void cvx_lm_options_levmar(cvx_lm_options *o);   /* lm.hpp:43-50,61 */
@@ -202,8 +202,9 @@ int cvx_calib_inner_ordering(int n_cameras, int n_views, int n_points, const int
                              const int *point_id, int fix_intrinsics, int fix_points, int *group, int *n_sets);
 /* One pass of CoordinateDescentMinimizer::Minimize on the handle's current parameters, in place: set after set,
  * every block is minimised over its own residual blocks by an LM with Ceres' default options, all blocks of a set
- * at once on the device (inner_kernels.h).  *cost (may be NULL) receives 1/2 sum r^2 afterwards.  What
- * cvx_calib_solve runs on every candidate while opt->inner_iterations is set and the passes still pay. */
+ * at once on the device (inner_kernels.h).  *cost (may be NULL) receives 1/2 sum r^2 afterwards (over this rank's
+ * observations, as cvx_calib_cost).  What cvx_calib_solve runs on every candidate while opt->inner_iterations is set
+ * and the passes still pay.  On a view-sharded handle it is a collective: every rank calls it. */
 int cvx_calib_inner_pass(cvx_calib *h, double *cost);
 
 /* value CameraCalibration::refine returns: sqrt(total_cost / (2 n_obs)), calibration.cpp:463 */

@@ -86,30 +86,6 @@ def test_refine_with_inner_iterations_follows_the_oracle(orc, case):
     g.close()
 
 
-def test_view_sharded_handles_refuse_inner_iterations():
-    """A block's observations are spread over the ranks of a view-sharded run; the passes are not restated for that
-    (include/cvx_amd.h): the solve says so before doing any work, and runs with the flag cleared."""
-    d = cvx_amd.synth_calib(1, 6, 9, 6, 13)
-    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 1, 54)
-    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
-    calls = []
-
-    def hook(ctx, buf, count, on_device, stream):      # a second rank that contributes nothing
-        calls.append(count)
-        return 0
-    cb = capi.ALLREDUCE_FN(hook)
-    g.set_exchange(cb, 0, 2, device_buffers=False)
-    with pytest.raises(capi.CvxError) as e:
-        g.solve(capi.options("refine"))
-    assert e.value.status == 4 and not calls            # CVX_ERR_UNSUPPORTED, nothing exchanged
-    with pytest.raises(capi.CvxError):
-        g.inner_pass()
-    o = capi.options("refine"); o.inner_iterations = 0
-    s = g.solve(o)
-    assert s.termination in (1, 2, 3) and calls
-    g.close()
-
-
 def test_config4_size_passes(orc):
     """BASELINE config 4 (8 cameras x 1 250 views x 108 corners = 1.08 M observations): the pass at full size through
     properties -- it descends, a second one gains little, each pose block ends where the oracle's LM on that block

@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 
 def sharded_options(capi):
-    """refine's options for view-sharded handles: inner iterations need a block's observations on one rank
-    (include/cvx_amd.h), so they are off here, on the sharded and on the single-rank side of every comparison"""
+    """refine's options without the inner iterations, on the sharded and on the single-rank side of the comparisons
+    of the LM iteration itself (the inner iterations on shards have a comparison of their own below)"""
     o = capi.options("refine")
     o.inner_iterations = 0
     return o
@@ -66,6 +66,20 @@ def _worker(rank, world, port, out):
     res["dev"] = {"it": s2.iterations, "term": s2.termination, "cost": s2.final_cost, "trace": s2.trace()["cost"].tolist(),
                   "intr": intr2.tolist(), "pts": pts2.tolist(), "poses": poses2.tolist()}
     g2.close()
+    # inner iterations (calibration.cpp:424) on shards: the ordering from the whole problem's structure (two
+    # exchanges at the first pass), the shared blocks' sums all-reduced every round; over both buffer protocols
+    for dev in (False, True):
+        g3 = cvx_amd.Calib(sh["cam_of_view"], sh["view_off"], sh["point_id"], sh["obs_x"], sh["obs_y"], d["C"], d["P"])
+        g3.set_exchange(cb2 if dev else cb, rank, world, device_buffers=dev)
+        g3.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
+        o3 = capi.options("refine")
+        assert o3.inner_iterations == 1
+        s3 = g3.solve(o3)
+        intr3, poses3, pts3 = g3.get_params()
+        res["inner_dev" if dev else "inner"] = {
+            "it": s3.iterations, "term": s3.termination, "cost": s3.final_cost, "trace": s3.trace()["cost"].tolist(),
+            "passes": s3.num_inner_iteration_steps, "intr": intr3.tolist(), "pts": pts3.tolist(), "poses": poses3.tolist()}
+        g3.close()
     # hand-eye shards by pair
     G, T, xg, x0 = cvx_amd.synth_handeye(40, 9)
     A, B = cvx_amd.handeye_pairs(G, T)
@@ -128,6 +142,22 @@ def test_two_rank_solve_equals_single_rank():
     assert abs(d0["cost"] - s.final_cost) <= 1e-11 * s.final_cost
     assert np.max(np.abs(np.array(d0["intr"]) - intr) / np.maximum(np.abs(intr), 1e-3)) < 1e-9
     assert np.max(np.abs(np.array(d0["pts"]) - pts)) < 1e-9 * np.max(np.abs(pts))
+    # with the inner iterations: the sharded runs follow the single-rank run pass for pass
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    si = g.solve(capi.options("refine"))
+    intr_i, poses_i, pts_i = g.get_params()
+    assert si.num_inner_iteration_steps >= 1
+    for key in ("inner", "inner_dev"):
+        a0, a1 = r0[key], r1[key]
+        assert a0["intr"] == a1["intr"] and a0["pts"] == a1["pts"] and a0["trace"] == a1["trace"]
+        assert (a0["it"], a0["term"], a0["passes"]) == (si.iterations, si.termination, si.num_inner_iteration_steps)
+        tri = np.array(a0["trace"])
+        assert np.all(np.abs(tri - si.trace()["cost"]) <= 1e-10 * tri)
+        assert abs(a0["cost"] - si.final_cost) <= 1e-11 * si.final_cost
+        assert np.max(np.abs(np.array(a0["intr"]) - intr_i) / np.maximum(np.abs(intr_i), 1e-3)) < 1e-9
+        assert np.max(np.abs(np.array(a0["pts"]) - pts_i)) < 1e-9 * np.max(np.abs(pts_i))
+        got = np.concatenate([np.array(a0["poses"]), np.array(a1["poses"])])
+        assert np.max(np.abs(got - poses_i)) < 1e-8 * np.max(np.abs(poses_i))
     got_poses = np.concatenate([np.array(d0["poses"]), np.array(d1["poses"])])
     assert np.max(np.abs(got_poses - poses)) < 1e-8 * np.max(np.abs(poses))
     # hand-eye
