@@ -206,6 +206,7 @@ def toolba_bench(cvx_amd, torch, device, with_cpu, V=CAMERAS * VIEWS_PER_CAMERA,
     g = ToolBA(view_off, pid, ox, oy, trans, intr, P, device=device)
     op = capi.options("toolba")
     op.max_iterations = 10
+    op.inner_iterations = 0      # the LM iteration itself, as for refine above
     g.solve(p0, X, op)
     torch.cuda.synchronize()
     reps = 5
@@ -221,7 +222,7 @@ def toolba_bench(cvx_amd, torch, device, with_cpu, V=CAMERAS * VIEWS_PER_CAMERA,
         from oracle import oracle as orc
         Vs = V
         o = orc.ToolBA(view_off[:Vs + 1], pid[:Vs * P], ox[:Vs * P], oy[:Vs * P], trans[:Vs], intr, P)
-        oo = orc.options("toolba"); oo.max_iterations = 5
+        oo = orc.options("toolba"); oo.max_iterations = 5; oo.inner_iterations = 0
         t = time.perf_counter()
         so = o.solve(p0, X, oo)[2]
         dtc = time.perf_counter() - t

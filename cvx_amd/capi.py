@@ -106,6 +106,7 @@ SIGNATURES = {
     "cvx_calib_num_shared": (C.c_int, [C.c_void_p]),
     "cvx_calib_cost": (C.c_int, [C.c_void_p, dp]),
     "cvx_calib_inner_pass": (C.c_int, [C.c_void_p, dp]),
+    "cvx_toolba_inner_pass": (C.c_int, [C.c_void_p, dp, dp, dp]),
     "cvx_calib_inner_ordering": (C.c_int, [C.c_int, C.c_int, C.c_int, ip, ip, ip, C.c_int, C.c_int, ip, ip]),
     "cvx_calib_evaluate": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp]),
     "cvx_calib_evaluate_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -137,6 +137,81 @@ void chol3_solve(const double l[6], double b[3]) {
     b[0] = (b[0] - l[1] * b[1] - l[2] * b[2]) / l[0];
 }
 
+// ---- inner iterations (use_inner_iterations = true, hand_eye_registration.cpp:205) ----
+// The parameter blocks of the reference's problem are q (4 numbers, QuaternionParameterization), t (3) and the board
+// points (:176-181), all with three degrees of freedom; every residual block touches q, t and one point.  One LM
+// state per block, the state machine of inner_kernels.h (k_inner_solve / k_inner_decide) on the host: the block
+// sums come from the device kernels the outer iteration uses (all-reduced there when the views are sharded, so
+// every rank walks through the same decisions).
+struct BlockLM3 {
+    double cost = 0, radius = 1e4, decrease = 2.0, model = 0, s2[3] = {1, 1, 1};
+    double H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};     // upper triangle a00 a01 a02 a11 a12 a22
+    double xc[4] = {0, 0, 0, 0};
+    int iters = 0, invalid = 0, term = 0;
+    bool first = true, has_candidate = false, needs_lin = true, done = false;
+
+    // after a linearisation at x: tests, then the damped step; x has ng numbers, plus() makes the candidate
+    template <class Plus>
+    void solve(const double *x, int ng, Plus plus) {
+        has_candidate = false;
+        if (needs_lin) {
+            if (first) {
+                const double dg[3] = {H[0], H[3], H[5]};
+                for (int i = 0; i < 3; ++i) { const double s = 1.0 / (1.0 + std::sqrt(dg[i])); s2[i] = s * s; }
+                first = false;
+            }
+            double gmax = 0;
+            for (int i = 0; i < 3; ++i) gmax = std::max(gmax, std::fabs(g[i]));
+            if (gmax <= 1e-10) { term = 1; done = true; return; }
+            needs_lin = false;
+        }
+        const double dg[3] = {H[0], H[3], H[5]};
+        for (;;) {
+            if (iters >= 50) { term = 4; done = true; return; }
+            ++iters;
+            double D[3], l[6] = {H[0], H[1], H[2], H[3], H[4], H[5]}, d[3] = {-g[0], -g[1], -g[2]};
+            for (int i = 0; i < 3; ++i) D[i] = std::min(std::max(s2[i] * dg[i], 1e-6), 1e32) / (s2[i] * radius);
+            l[0] += D[0]; l[3] += D[1]; l[5] += D[2];
+            double mc = 0;
+            const bool ok = chol3(l);
+            if (ok) {
+                chol3_solve(l, d);
+                for (int i = 0; i < 3; ++i) mc += d[i] * (D[i] * d[i] - g[i]);
+                mc *= 0.5;
+            }
+            if (!ok || !(mc > 0.0)) {
+                if (++invalid >= 5) { term = 6; done = true; return; }
+                radius *= 0.5;
+                continue;
+            }
+            invalid = 0;
+            plus(x, d, xc);
+            double sn = 0, xn = 0;
+            for (int i = 0; i < ng; ++i) { sn += (x[i] - xc[i]) * (x[i] - xc[i]); xn += x[i] * x[i]; }
+            if (std::sqrt(sn) <= 1e-8 * (std::sqrt(xn) + 1e-8)) { term = 2; done = true; return; }
+            model = mc;
+            has_candidate = true;
+            return;
+        }
+    }
+    // with the candidate's cost: true when the block moves to its candidate
+    bool decide(double cand) {
+        has_candidate = false;
+        if (std::fabs(cost - cand) <= 1e-6 * cost) { term = 3; done = true; return false; }
+        const double rho = (cost - cand) / model;
+        if (rho > 1e-3) {
+            const double t = 2.0 * rho - 1.0;
+            radius = std::min(radius / std::max(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+            decrease = 2.0;
+            needs_lin = true;
+            return true;
+        }
+        radius /= decrease; decrease *= 2.0;
+        if (radius < 1e-32) { term = 5; done = true; }
+        return false;
+    }
+};
+
 class ToolBAEvaluator : public cvx::Evaluator {
 public:
     ToolBAEvaluator(cvx_toolba *h_, const double *p, const double *pts) : h(h_), P(h_->P), nf(6 + 3 * h_->P), ng(7 + 3 * h_->P) {
@@ -282,6 +357,109 @@ public:
         lin_valid = false;
         return CVX_OK;
     }
+
+    // ---- one pass of CoordinateDescentMinimizer::Minimize over the candidate xc ----
+    // pose-side sums of the per-point blocks in h_out: upper triangle of the 6 x 6 block (21) | gradient (6) | 2 cost
+    void pose_sums(double up[27], double *c) const {
+        for (int k = 0; k < 27; ++k) up[k] = 0.0;
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) { const double *b = blk(p); for (int k = 0; k < 27; ++k) up[k] += b[k]; s += b[54]; }
+        *c = 0.5 * s;
+    }
+    // block q (which = 0: tangent 0..2 of the pose) or t (which = 1: tangent 3..5), minimised alone
+    int inner_pose_block(int which) {
+        BlockLM3 lm;
+        double *xb = xc.data() + (which ? 4 : 0);
+        const int ng = which ? 3 : 4;
+        for (int round = 0; round < 64 && !lm.done; ++round) {
+            if (lm.needs_lin) {
+                int st = device_blocks(h, xc.data());
+                if (st) return st;
+                double up[27];
+                pose_sums(up, &lm.cost);
+                // upper-triangle index of (a, b), a <= b, in a 6 x 6: a * 6 - a (a - 1) / 2 + (b - a)
+                auto ut = [&](int a, int b) { return up[a * 6 - a * (a - 1) / 2 + (b - a)]; };
+                const int o = which ? 3 : 0;
+                lm.H[0] = ut(o, o); lm.H[1] = ut(o, o + 1); lm.H[2] = ut(o, o + 2);
+                lm.H[3] = ut(o + 1, o + 1); lm.H[4] = ut(o + 1, o + 2); lm.H[5] = ut(o + 2, o + 2);
+                for (int i = 0; i < 3; ++i) lm.g[i] = up[21 + o + i];
+            }
+            if (which) lm.solve(xb, ng, [](const double *x0, const double *d, double *out) { for (int i = 0; i < 3; ++i) out[i] = x0[i] + d[i]; });
+            else lm.solve(xb, ng, [](const double *x0, const double *d, double *out) { quaternion_plus(x0, d, out); });
+            if (!lm.has_candidate) continue;
+            std::vector<double> y = xc;
+            for (int i = 0; i < ng; ++i) y[(which ? 4 : 0) + i] = lm.xc[i];
+            double cand = 0;
+            int st = device_cost(h, y.data(), &cand);
+            if (st) return st;
+            if (lm.decide(cand)) xc = y;
+        }
+        return CVX_OK;
+    }
+    // all point blocks at once, each with its own LM state; a round costs two block evaluations
+    int inner_points() {
+        std::vector<BlockLM3> lm(P);
+        std::vector<double> y;
+        for (int p = 0; p < P; ++p) lm[p].done = !used[p];
+        for (int round = 0; round < 64; ++round) {
+            bool any = false;
+            for (int p = 0; p < P; ++p) any = any || !lm[p].done;
+            if (!any) break;
+            int st = device_blocks(h, xc.data());
+            if (st) return st;
+            y = xc;
+            bool cands = false;
+            for (int p = 0; p < P; ++p) {
+                BlockLM3 &b = lm[p];
+                if (b.done) continue;
+                if (b.needs_lin) {
+                    const double *k = blk(p);
+                    for (int i = 0; i < 6; ++i) b.H[i] = k[45 + i];
+                    for (int i = 0; i < 3; ++i) b.g[i] = k[51 + i];
+                    b.cost = 0.5 * k[54];
+                }
+                b.solve(xc.data() + 7 + 3 * p, 3, [](const double *x0, const double *d, double *out) { for (int i = 0; i < 3; ++i) out[i] = x0[i] + d[i]; });
+                if (b.has_candidate) { for (int i = 0; i < 3; ++i) y[7 + 3 * p + i] = b.xc[i]; cands = true; }
+            }
+            if (!cands) continue;
+            st = device_blocks(h, y.data());        // a point's cost depends on its own coordinates only
+            if (st) return st;
+            for (int p = 0; p < P; ++p) {
+                BlockLM3 &b = lm[p];
+                if (b.done || !b.has_candidate) continue;
+                if (b.decide(0.5 * blk(p)[54]))
+                    for (int i = 0; i < 3; ++i) xc[7 + 3 * p + i] = y[7 + 3 * p + i];
+            }
+        }
+        return CVX_OK;
+    }
+    std::vector<char> used;      // points that occur in a residual block
+    int n_used = -1;
+    int inner_iterations(double *cost_out, double *step_norm2) override {
+        if (n_used < 0) {
+            used.assign(P, 0);
+            n_used = 0;
+            int st = device_blocks(h, xc.data());
+            if (st) return st;
+            // a point without observations has an empty block: its diagonal and cost sums are exactly zero
+            for (int p = 0; p < P; ++p) { const double *k = blk(p); used[p] = (k[45] != 0.0 || k[48] != 0.0 || k[50] != 0.0 || k[54] != 0.0); n_used += used[p]; }
+        }
+        // Ceres' automatic ordering on this graph (oracle/cvx_oracle.c, orc_toolba_inner_pass): t, q, points; with
+        // a single point in use: the point, t, q
+        int st = CVX_OK;
+        if (n_used == 1) st = inner_points();
+        if (!st && n_used > 0) st = inner_pose_block(1);
+        if (!st && n_used > 0) st = inner_pose_block(0);
+        if (!st && n_used > 1) st = inner_points();
+        if (st) return st;
+        st = device_cost(h, xc.data(), cost_out);
+        if (st) return st;
+        double sn = 0;
+        for (int i = 0; i < ng; ++i) sn += (x[i] - xc[i]) * (x[i] - xc[i]);
+        *step_norm2 = sn;
+        lin_valid = false;       // h_out holds the blocks of another point now
+        return CVX_OK;
+    }
     std::vector<double> xbest;
     int save_best() override { xbest = x; return CVX_OK; }
     int restore_best() override {
@@ -295,8 +473,7 @@ public:
 }  // namespace
 
 extern "C" void cvx_lm_options_toolba(cvx_lm_options *o) {     // hand_eye_registration.cpp:201-210
-    cvx_lm_options_refine(o);
-    o->inner_iterations = 0;        // :205 sets use_inner_iterations too; restated for refine's problem only
+    cvx_lm_options_refine(o);      // use_inner_iterations (:205) as in refine
     o->nonmonotonic = 0;
     o->function_tolerance = o->gradient_tolerance = o->parameter_tolerance = 1e-20;
 }
@@ -415,6 +592,20 @@ extern "C" int cvx_toolba_normal_eq(cvx_toolba *h, const double p[7], const doub
         if (gx) for (int k = 0; k < 3; ++k) gx[3 * (size_t)q + k] = b[51 + k];
     }
     if (cost) *cost = ev.cost;
+    return CVX_OK;
+}
+
+extern "C" int cvx_toolba_inner_pass(cvx_toolba *h, double p[7], double *points, double *cost) {
+    if (!h || !p || !points) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    ToolBAEvaluator ev(h, p, points);
+    ev.xc = ev.x;
+    double c = 0, n2 = 0;
+    int st = ev.inner_iterations(&c, &n2);
+    if (st) return st;
+    std::memcpy(p, ev.xc.data(), 7 * sizeof(double));
+    std::memcpy(points, ev.xc.data() + 7, sizeof(double) * 3 * (size_t)h->P);
+    if (cost) *cost = c;
     return CVX_OK;
 }
 

@@ -348,6 +348,12 @@ class ToolBA:
               "cvx_toolba_normal_eq")
         return Hpp, gp, W, U, gx, c.value
 
+    def inner_pass(self, p, points):
+        """one pass of Ceres' inner iterations over the blocks q, t and every point -> (p, points, cost)"""
+        p, points = f64(p).copy(), f64(points).copy(); c = C.c_double()
+        check(lib().cvx_toolba_inner_pass(self.h, pd(p), pd(points), C.byref(c)), "cvx_toolba_inner_pass")
+        return p, points, c.value
+
     def solve(self, p, points, options):
         p, points = f64(p).copy(), f64(points).copy(); s = capi.LMSummary()
         check(lib().cvx_toolba_solve(self.h, pd(p), pd(points), C.byref(options), C.byref(s)), "cvx_toolba_solve")

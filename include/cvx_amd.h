@@ -61,9 +61,10 @@ typedef struct {
     int nonmonotonic;
     int max_consecutive_nonmonotonic_steps;
     double tau, eps1, eps2, eps3;
-    int inner_iterations;               /* Solver::Options::use_inner_iterations (calibration.cpp:424); strategy 0 of
-                                           cvx_calib_solve only: the other solves return CVX_ERR_UNSUPPORTED with it,
-                                           strategy 1 ignores it */
+    int inner_iterations;               /* Solver::Options::use_inner_iterations (calibration.cpp:424,
+                                           hand_eye_registration.cpp:205); strategy 0 of cvx_calib_solve and
+                                           cvx_toolba_solve: cvx_handeye_solve returns CVX_ERR_UNSUPPORTED with it
+                                           (one block, handeye.cpp:315), strategy 1 ignores it */
     double inner_iteration_tolerance;   /* Ceres default 1e-3 */
 } cvx_lm_options;
 
@@ -322,6 +323,11 @@ int cvx_toolba_cost(cvx_toolba *h, const double p[7], const double *points, doub
  * U[n_points][3][3], gx[n_points][3]; any may be NULL */
 int cvx_toolba_normal_eq(cvx_toolba *h, const double p[7], const double *points, double Hpp[36], double gp[6],
                          double *W, double *U, double *gx, double *cost);
+/* one inner-iteration pass (use_inner_iterations, :205) on (p, points) in place: the blocks q, t and every point in
+ * the order Ceres' automatic ordering gives them (t, q, then all points; with one point in use: the point, t, q),
+ * each minimised alone by an LM with Ceres' default options; *cost (may be NULL) = 1/2 sum rho afterwards.  What
+ * cvx_toolba_solve runs on every candidate while the passes pay (cvx_lm_options_toolba sets inner_iterations). */
+int cvx_toolba_inner_pass(cvx_toolba *h, double p[7], double *points, double *cost);
 /* ceres::Solve of :213-214; p and points in/out (the caller inverts the pose as :229-230 does) */
 int cvx_toolba_solve(cvx_toolba *h, double p[7], double *points, const cvx_lm_options *opt, cvx_lm_summary *summary);
 

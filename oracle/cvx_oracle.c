@@ -1704,6 +1704,7 @@ void orc_lm_options_toolba(orc_lm_options *o) {   /* hand_eye_registration.cpp:2
     o->nonmonotonic = 0;
     o->max_iterations = 100;
     o->function_tolerance = 1e-20; o->gradient_tolerance = 1e-20; o->parameter_tolerance = 1e-20;
+    o->inner_iterations = 1;            /* :205 */
 }
 
 typedef struct { const orc_toolba_problem *pb; int nf; double *H, *g, *A; } tba_ctx;
@@ -1728,13 +1729,108 @@ static void tba_m_plus(void *vc, const double *x, const double *delta, double *x
 static double tba_m_cost(void *vc, const double *x) { tba_ctx *c = vc; return orc_toolba_cost(c->pb, x, x + 7); }
 static double tba_m_free_norm2(void *vc, const double *x) { tba_ctx *c = vc; double s = 0; for (int i = 0; i < 7 + 3 * c->pb->P; ++i) s += x[i] * x[i]; return s; }
 
+/* ---- inner iterations of the tool-level BA (use_inner_iterations = true, hand_eye_registration.cpp:205).  The
+ * parameter blocks are q (4, QuaternionParameterization), t (3) and the points (:176-181); every residual block
+ * touches q, t and one point, so Ceres' automatic ordering (see orc_calib_inner_ordering) is: with two or more
+ * points in use the points have the lowest degree (2 < 1 + points) and go first, then q (named before t), then t;
+ * reversed: t, q, points.  With a single point all three degrees tie and the naming order decides: q, then t, then
+ * the point; reversed: the point, t, q. */
+typedef struct { const orc_toolba_problem *pb; const double *x; int type, index; double H[9], g[3]; } tbi_ctx;   /* type 0 t, 1 q, 2 point */
+
+static void tbi_visit(tbi_ctx *c, const double *xb, double *cost, double *H, double *g) {
+    const orc_toolba_problem *pb = c->pb;
+    double p[7], Pq[12], s = 0;
+    memcpy(p, c->x, sizeof p);
+    if (c->type == 0) memcpy(p + 4, xb, 3 * sizeof(double));
+    if (c->type == 1) memcpy(p, xb, 4 * sizeof(double));
+    quat_plus_jac(p, Pq);
+    if (H) { memset(H, 0, 9 * sizeof(double)); memset(g, 0, 3 * sizeof(double)); }
+    for (int v = 0; v < pb->V; ++v)
+        for (int o = pb->view_off[v]; o < pb->view_off[v + 1]; ++o) {
+            const int pid = pb->point_id[o];
+            if (c->type == 2 && pid != c->index) continue;
+            const double *X = c->type == 2 ? xb : c->x + 7 + 3 * pid;
+            double r[2], Jq[8], Jt[6], Jx[6], rho[3];
+            orc_toolba_analytic(pb->intr, pb->trans + 12 * v, p, p + 4, X, pb->obs_x[o], pb->obs_y[o], r, Jq, Jt, Jx);
+            orc_huber(pb->huber, r[0] * r[0] + r[1] * r[1], rho);
+            s += rho[0];
+            if (!H) continue;
+            const double w = sqrt(rho[1]);
+            for (int k = 0; k < 2; ++k) {
+                double row[3];
+                for (int a = 0; a < 3; ++a)
+                    row[a] = c->type == 0 ? w * Jt[k * 3 + a] : c->type == 2 ? w * Jx[k * 3 + a]
+                           : w * (Jq[k * 4] * Pq[a] + Jq[k * 4 + 1] * Pq[3 + a] + Jq[k * 4 + 2] * Pq[6 + a] + Jq[k * 4 + 3] * Pq[9 + a]);
+                for (int a = 0; a < 3; ++a) {
+                    g[a] += row[a] * w * r[k];
+                    for (int b = 0; b < 3; ++b) H[a * 3 + b] += row[a] * row[b];
+                }
+            }
+        }
+    *cost = 0.5 * s;
+}
+static double tbi_linearize(void *vc, const double *x, double *diag, double *grad) {
+    tbi_ctx *c = vc; double cost;
+    tbi_visit(c, x, &cost, c->H, c->g);
+    for (int i = 0; i < 3; ++i) { diag[i] = c->H[i * 3 + i]; grad[i] = c->g[i]; }
+    return cost;
+}
+static int tbi_solve(void *vc, const double *D, double *delta) {
+    tbi_ctx *c = vc; double A[9];
+    memcpy(A, c->H, sizeof A);
+    for (int i = 0; i < 3; ++i) { A[i * 3 + i] += D[i]; delta[i] = -c->g[i]; }
+    return orc_cholesky_solve(3, A, delta);
+}
+static void tbi_plus(void *vc, const double *x, const double *delta, double *xo) {
+    tbi_ctx *c = vc;
+    if (c->type == 1) orc_quaternion_plus(x, delta, xo);
+    else for (int i = 0; i < 3; ++i) xo[i] = x[i] + delta[i];
+}
+static double tbi_cost(void *vc, const double *x) { tbi_ctx *c = vc; double cost; tbi_visit(c, x, &cost, 0, 0); return cost; }
+static double tbi_norm2(void *vc, const double *x) { tbi_ctx *c = vc; double s = 0; for (int i = 0; i < (c->type == 1 ? 4 : 3); ++i) s += x[i] * x[i]; return s; }
+
+double orc_toolba_inner_pass(const orc_toolba_problem *pb, double p[7], double *points) {
+    const int ng = 7 + 3 * pb->P;
+    double *x = malloc(sizeof(double) * ng);
+    memcpy(x, p, 7 * sizeof(double)); memcpy(x + 7, points, sizeof(double) * 3 * pb->P);
+    char *used = calloc(pb->P ? pb->P : 1, 1);
+    int n_used = 0;
+    for (int o = 0; o < pb->N; ++o) if (!used[pb->point_id[o]]) { used[pb->point_id[o]] = 1; ++n_used; }
+    orc_lm_options io; lm_defaults(&io);
+    orc_lm_summary *isum = malloc(sizeof *isum);
+    /* the order of the sets, as block types: 0 t, 1 q, 2 points */
+    int order[3] = { 0, 1, 2 };
+    if (n_used == 1) { order[0] = 2; order[1] = 0; order[2] = 1; }
+    for (int k = 0; k < 3 && n_used > 0; ++k) {
+        const int type = order[k];
+        for (int idx = 0; idx < (type == 2 ? pb->P : 1); ++idx) {
+            if (type == 2 && !used[idx]) continue;
+            tbi_ctx c; memset(&c, 0, sizeof c);
+            c.pb = pb; c.x = x; c.type = type; c.index = idx;
+            double *xb = type == 0 ? x + 4 : type == 1 ? x : x + 7 + 3 * idx;
+            const int nglob = type == 1 ? 4 : 3;
+            double xloc[4];
+            memcpy(xloc, xb, sizeof(double) * nglob);
+            lm_model m = { &c, 3, nglob, tbi_linearize, tbi_solve, tbi_plus, tbi_cost, tbi_norm2, NULL };
+            lm_ceres(&m, xloc, &io, isum);
+            memcpy(xb, xloc, sizeof(double) * nglob);
+        }
+    }
+    memcpy(p, x, 7 * sizeof(double)); memcpy(points, x + 7, sizeof(double) * 3 * pb->P);
+    const double cost = orc_toolba_cost(pb, p, points);
+    free(x); free(used); free(isum);
+    return cost;
+}
+
+static double tba_m_inner(void *vc, double *x) { tba_ctx *c = vc; return orc_toolba_inner_pass(c->pb, x, x + 7); }
+
 int orc_toolba_solve(const orc_toolba_problem *pb, double p[7], double *points, const orc_lm_options *opt,
                      orc_lm_summary *sum) {
     const int nf = 6 + 3 * pb->P, ng = 7 + 3 * pb->P;
     tba_ctx c = { pb, nf, malloc(sizeof(double) * (size_t)nf * nf), malloc(sizeof(double) * nf), malloc(sizeof(double) * (size_t)nf * nf) };
     double *x = malloc(sizeof(double) * ng);
     memcpy(x, p, 7 * sizeof(double)); memcpy(x + 7, points, sizeof(double) * 3 * pb->P);
-    lm_model m = { &c, nf, ng, tba_m_linearize, tba_m_solve, tba_m_plus, tba_m_cost, tba_m_free_norm2 };
+    lm_model m = { &c, nf, ng, tba_m_linearize, tba_m_solve, tba_m_plus, tba_m_cost, tba_m_free_norm2, tba_m_inner };
     const int term = (opt->strategy == 1) ? lm_nielsen(&m, x, opt, sum) : lm_ceres(&m, x, opt, sum);
     memcpy(p, x, 7 * sizeof(double)); memcpy(points, x + 7, sizeof(double) * 3 * pb->P);
     free(c.H); free(c.g); free(c.A); free(x);

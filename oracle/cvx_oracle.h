@@ -203,6 +203,9 @@ double orc_toolba_cost(const orc_toolba_problem *pb, const double p[7], const do
 void orc_toolba_normal_eq(const orc_toolba_problem *pb, const double p[7], const double *points, double *H, double *g,
                           double *cost);
 void orc_lm_options_toolba(orc_lm_options *o);   /* hand_eye_registration.cpp:201-210 */
+/* one inner-iteration pass (:205; blocks q, t and every point, in Ceres' automatic order) on (p, points) in place;
+ * returns the cost afterwards */
+double orc_toolba_inner_pass(const orc_toolba_problem *pb, double p[7], double *points);
 int orc_toolba_solve(const orc_toolba_problem *pb, double p[7], double *points, const orc_lm_options *opt,
                      orc_lm_summary *sum);
 

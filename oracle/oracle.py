@@ -128,6 +128,7 @@ def lib():
         L.orc_lm_options_toolba.argtypes = [C.POINTER(LMOptions)]
         L.orc_toolba_solve.argtypes = [tp, dp, dp, C.POINTER(LMOptions), C.POINTER(LMSummary)]
         L.orc_toolba_solve.restype = C.c_int
+        L.orc_toolba_inner_pass.argtypes = [tp, dp, dp]; L.orc_toolba_inner_pass.restype = C.c_double
         fp = C.POINTER(C.c_float)
         L.orc_homography_lm.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, dp, C.c_int, dp, dp]
         L.orc_homography_lm.restype = C.c_int
@@ -276,6 +277,11 @@ class ToolBA:
         H = np.zeros((self.nf, self.nf)); g = np.zeros(self.nf); cost = C.c_double()
         lib().orc_toolba_normal_eq(C.byref(self.pb), _dp(p), _dp(points), _dp(H), _dp(g), C.byref(cost))
         return H, g, cost.value
+
+    def inner_pass(self, p, points):
+        p, points = f64(p).copy(), f64(points).copy()
+        c = lib().orc_toolba_inner_pass(C.byref(self.pb), _dp(p), _dp(points))
+        return p, points, c
 
     def solve(self, p, points, options):
         p, points = f64(p).copy(), f64(points).copy(); s = LMSummary()

@@ -52,6 +52,9 @@ def test_solve_follows_the_oracle(orc, V, ragged, outliers):
     po, xo, so = o.solve(d["p0"], d["points"], orc.options("toolba"))
     pg, xg, sg = g.solve(d["p0"], d["points"], capi.options("toolba"))
     assert abs(sg.initial_cost - so.initial_cost) <= 1e-12 * so.initial_cost
+    # use_inner_iterations (hand_eye_registration.cpp:205): the same candidates go through a pass on either side
+    assert capi.options("toolba").inner_iterations == 1 and orc.options("toolba").inner_iterations == 1
+    assert sg.num_inner_iteration_steps == so.num_inner_iteration_steps >= 1
     # tolerances of 1e-20 make the last iterations a matter of rounding: compare the common prefix of the traces
     n = min(sg.trace_len, so.trace_len, 12)
     tg, to = np.array(sg.trace_cost[:n]), np.array(so.trace_cost[:n])
@@ -59,6 +62,50 @@ def test_solve_follows_the_oracle(orc, V, ragged, outliers):
     assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.final_cost
     assert np.max(np.abs(pg - po)) <= 1e-8 and np.max(np.abs(xg - xo)) <= 1e-8
     assert sg.final_cost < 0.3 * sg.initial_cost
+
+
+@pytest.mark.parametrize("V,ragged,outliers", [(30, 0, 0.03), (60, 4, 0.08)])
+def test_inner_pass_matches_the_oracle(orc, V, ragged, outliers):
+    """One coordinate-descent pass over the blocks t, q and every point (Ceres' automatic ordering on this graph),
+    each block's own LM to its own termination, twice in a row; and the solve without the passes ends at the same
+    cost."""
+    rng = np.random.default_rng(200 + V)
+    d = toolba_problem(rng, V, ragged=ragged, outliers=outliers)
+    g, o = _pair(orc, d)
+    c0 = g.cost(d["p0"], d["points"])
+    po, xo, co = o.inner_pass(d["p0"], d["points"])
+    pg, xg, cg = g.inner_pass(d["p0"], d["points"])
+    assert cg < c0 and abs(cg - co) <= 1e-10 * co
+    assert np.max(np.abs(pg - po)) <= 1e-10 and np.max(np.abs(xg - xo)) <= 1e-10 * np.max(np.abs(xo))
+    assert abs(g.cost(pg, xg) - cg) <= 1e-13 * cg
+    po2, xo2, co2 = o.inner_pass(po, xo)
+    pg2, xg2, cg2 = g.inner_pass(pg, xg)
+    assert cg2 <= cg and abs(cg2 - co2) <= 1e-10 * co2
+    assert np.max(np.abs(pg2 - po2)) <= 1e-9 and np.max(np.abs(xg2 - xo2)) <= 1e-9 * np.max(np.abs(xo2))
+    op = capi.options("toolba"); op.max_iterations = 40
+    _, _, s1 = g.solve(d["p0"], d["points"], op)
+    op.inner_iterations = 0
+    _, _, s0 = g.solve(d["p0"], d["points"], op)
+    assert s1.num_inner_iteration_steps >= 1 and s0.num_inner_iteration_steps == 0
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-8 * s0.final_cost
+
+
+def test_inner_pass_with_a_single_point_in_use(orc):
+    """With one point all three degrees of the Hessian graph tie and the naming order decides: the point first,
+    then t, then q."""
+    rng = np.random.default_rng(14)
+    d = toolba_problem(rng, 12)
+    keep = d["point_id"] == 20
+    view_of = np.repeat(np.arange(12), np.diff(d["view_off"]))
+    vo = np.concatenate([[0], np.cumsum(np.bincount(view_of[keep], minlength=12))]).astype(np.int32)
+    d2 = dict(d, view_off=vo, point_id=d["point_id"][keep], obs_x=d["obs_x"][keep], obs_y=d["obs_y"][keep])
+    g, o = _pair(orc, d2)
+    po, xo, co = o.inner_pass(d["p0"], d["points"])
+    pg, xg, cg = g.inner_pass(d["p0"], d["points"])
+    assert abs(cg - co) <= 1e-9 * max(co, 1e-12) + 1e-18
+    assert np.max(np.abs(pg - po)) <= 1e-8 and np.max(np.abs(xg - xo)) <= 1e-8 * np.max(np.abs(xo))
+    moved = np.any(xg != d["points"], axis=1)
+    assert moved[20] and not np.any(np.delete(moved, 20))
 
 
 def test_repeated_runs_are_bitwise_identical(orc):
