@@ -444,8 +444,9 @@ public:
             // a point without observations has an empty block: its diagonal and cost sums are exactly zero
             for (int p = 0; p < P; ++p) { const double *k = blk(p); used[p] = (k[45] != 0.0 || k[48] != 0.0 || k[50] != 0.0 || k[54] != 0.0); n_used += used[p]; }
         }
-        // Ceres' automatic ordering on this graph (oracle/cvx_oracle.c, orc_toolba_inner_pass): t, q, points; with
-        // a single point in use: the point, t, q
+        // Ceres' automatic ordering on this graph (greedy independent sets by ascending degree, reversed: the points
+        // have degree 2, q and t degree 1 + points, q is named before t): t, q, points; with a single point in use
+        // all degrees tie and the naming order gives: the point, t, q
         int st = CVX_OK;
         if (n_used == 1) st = inner_points();
         if (!st && n_used > 0) st = inner_pose_block(1);
