@@ -99,7 +99,8 @@ struct cvx_calib {
     double *d_ib_active = nullptr, *d_ib_X = nullptr;   // blocks that go on; exchange buffer of the shared blocks' sums
     std::vector<double> x_stage;     // host staging of an exchange over a host-buffer hook
     double *d_ib_H = nullptr, *d_ib_st = nullptr, *d_ib_xc = nullptr, *d_ib_cc = nullptr, *d_ib_slab = nullptr, *d_ib_out = nullptr;
-    double *d_ib_ptslab = nullptr;
+    double *d_ib_ptslab = nullptr, *d_pt_ox = nullptr, *d_pt_oy = nullptr;
+    int *d_pt_view = nullptr, *d_pt_cam = nullptr;
     int pt_slices = 1;               // workgroups per point block
     double *h_ib_active = nullptr;   // pinned: [0] blocks that go on, [1..2] step norm parts
     // exchange
@@ -124,7 +125,8 @@ cvx_calib::~cvx_calib() {
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_pt_off, d_pt_obs, d_blk_group,
-                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out, d_ib_ptslab, d_ib_X};
+                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out, d_ib_ptslab, d_ib_X, d_pt_ox, d_pt_oy,
+                    d_pt_view, d_pt_cam};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -361,9 +363,10 @@ int exchange_sum_host(cvx_calib *h, std::vector<double> &v) {
 
 void free_inner(cvx_calib *h) {
     void *ptrs[] = {h->d_pt_off, h->d_pt_obs, h->d_blk_group, h->d_ib_flag, h->d_ib_active, h->d_ib_H, h->d_ib_st, h->d_ib_xc,
-                    h->d_ib_cc, h->d_ib_slab, h->d_ib_out, h->d_ib_ptslab, h->d_ib_X};
+                    h->d_ib_cc, h->d_ib_slab, h->d_ib_out, h->d_ib_ptslab, h->d_ib_X, h->d_pt_ox, h->d_pt_oy, h->d_pt_view, h->d_pt_cam};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    h->d_pt_ox = h->d_pt_oy = nullptr; h->d_pt_view = h->d_pt_cam = nullptr;
     h->d_pt_off = h->d_pt_obs = h->d_blk_group = h->d_ib_flag = nullptr;
     h->d_ib_active = h->d_ib_H = h->d_ib_st = h->d_ib_xc = h->d_ib_cc = h->d_ib_slab = h->d_ib_out = h->d_ib_ptslab = h->d_ib_X = nullptr;
     h->inner_ready = false;
@@ -431,8 +434,25 @@ int ensure_inner(cvx_calib *h) {
         for (int64_t o = 0; o < h->N; ++o) pt_obs[pos[point_id[o]]++] = (int)o;      // ascending observation = ascending view
     }
     hipStream_t s = h->stream;
+    // what a point block reads per observation, laid out in the order of its list
+    std::vector<int> pt_view((size_t)h->N), pt_cam((size_t)h->N);
+    std::vector<double> pt_ox((size_t)h->N), pt_oy((size_t)h->N), obs((size_t)h->N);
+    {
+        std::vector<int> view_of((size_t)h->N);
+        for (int v = 0; v < V; ++v)
+            for (int o = h->h_view_off[v]; o < h->h_view_off[v + 1]; ++o) view_of[o] = v;
+        for (int64_t k = 0; k < h->N; ++k) { pt_view[k] = view_of[pt_obs[k]]; pt_cam[k] = h->h_cam_of_view[pt_view[k]]; }
+        if (h->N) CVX_HIP(hipMemcpy(obs.data(), h->d_obs_x, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < h->N; ++k) pt_ox[k] = obs[pt_obs[k]];
+        if (h->N) CVX_HIP(hipMemcpy(obs.data(), h->d_obs_y, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < h->N; ++k) pt_oy[k] = obs[pt_obs[k]];
+    }
     st = dev_upload(&h->d_pt_off, pt_off.data(), pt_off.size(), s); if (st) return st;
     st = dev_upload(&h->d_pt_obs, pt_obs.data(), pt_obs.size(), s); if (st) return st;
+    st = dev_upload(&h->d_pt_view, pt_view.data(), pt_view.size(), s); if (st) return st;
+    st = dev_upload(&h->d_pt_cam, pt_cam.data(), pt_cam.size(), s); if (st) return st;
+    st = dev_upload(&h->d_pt_ox, pt_ox.data(), pt_ox.size(), s); if (st) return st;
+    st = dev_upload(&h->d_pt_oy, pt_oy.data(), pt_oy.size(), s); if (st) return st;
     st = dev_upload(&h->d_blk_group, group.data(), group.size(), s); if (st) return st;
     st = dev_alloc(&h->d_ib_flag, 4 * (size_t)NB); if (st) return st;
     st = dev_alloc(&h->d_ib_active, 1); if (st) return st;
@@ -468,6 +488,7 @@ int inner_pass(cvx_calib *h, int which) {
     cvxi::InnerArgs a;
     a.view_off = h->d_view_off; a.cam_of_view = h->d_cam_of_view; a.point_id = h->d_point_id; a.view_id = h->d_view_id;
     a.obs_x = h->d_obs_x; a.obs_y = h->d_obs_y; a.pt_off = h->d_pt_off; a.pt_obs = h->d_pt_obs;
+    a.pt_view = h->d_pt_view; a.pt_cam = h->d_pt_cam; a.pt_ox = h->d_pt_ox; a.pt_oy = h->d_pt_oy;
     a.grp_v0 = h->d_grp_v0; a.glist = h->d_glist; a.glist_off = h->d_glist_off;
     a.intr = h->d_intr[which]; a.points = h->d_points[which]; a.poses = h->d_poses[which]; a.rt = h->d_rt[which];
     a.blk_group = h->d_blk_group; a.H = h->d_ib_H; a.st = h->d_ib_st; a.xc = h->d_ib_xc; a.cc = h->d_ib_cc;

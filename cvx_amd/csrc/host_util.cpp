@@ -324,7 +324,10 @@ extern "C" int cvx_calib_inner_ordering(int C, int V, int P, const int *cam_of_v
                                         const int *point_id, int fix_intrinsics, int fix_points, int *group, int *n_sets) {
     if (C < 1 || V < 0 || P < 1 || !cam_of_view || !view_off || !group || !n_sets) return CVX_ERR_INVALID_ARG;
     const int NB = C + P + V;
-    const int64_t N = V ? view_off[V] : 0;
+    if (view_off[0] != 0) return CVX_ERR_INVALID_ARG;
+    for (int v = 0; v < V; ++v)
+        if (view_off[v + 1] < view_off[v]) return CVX_ERR_INVALID_ARG;
+    const int64_t N = view_off[V];
     if (N > 0 && !point_id) return CVX_ERR_INVALID_ARG;
     // observations by point; which camera sees which point; the views of a camera
     std::vector<int64_t> pt_off((size_t)P + 1, 0);

@@ -48,6 +48,9 @@ struct InnerArgs {
     const int *view_off, *cam_of_view, *point_id, *view_id;
     const double *obs_x, *obs_y;
     const int *pt_off, *pt_obs;              // observations by point
+    const int *pt_view;                      // in the order of pt_obs: the observation's view, its camera,
+    const int *pt_cam;
+    const double *pt_ox, *pt_oy;             // and the observed corner: a point block reads coalesced
     const int *grp_v0, *glist, *glist_off;   // K2's view groups (one camera each) and the per-camera lists of them
     // the point being improved (the trust-region candidate), and its rotation tables
     double *intr, *points, *poses;
@@ -113,7 +116,7 @@ __device__ __forceinline__ bool block_runs(const InnerArgs &a, int id, int want)
 // pose blocks: one wave per view.  MODE 0: H (21) | g (6) | cost at the block's pose; MODE 1: cost at the candidate
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ void __launch_bounds__(256) k_inner_pose(InnerArgs a) {
+__global__ void __launch_bounds__(256) k_inner_pose(InnerArgs a) {        // (held to 168 registers for a third wave: spills, 70 us)
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= a.V) return;
     const int id = a.C + a.P + v;
@@ -177,13 +180,14 @@ __global__ void __launch_bounds__(IP_THREADS) k_inner_point(InnerArgs a) {
     const long long off = a.pt_off[p], len = a.pt_off[p + 1] - off;
     const int k0 = (int)(off + len * sl / a.pt_slices), k1 = (int)(off + len * (sl + 1) / a.pt_slices);
     for (int k = k0 + threadIdx.x; k < k1; k += IP_THREADS) {
-        const int o = a.pt_obs[k], v = a.view_id[o];
-        const Intr in = load_intr(a.intr + 9 * a.cam_of_view[v]);
+        const int v = a.pt_view[k];
+        const double ox = a.pt_ox[k], oy = a.pt_oy[k];
+        const Intr in = load_intr(a.intr + 9 * a.pt_cam[k]);
         const double *rt = a.rt + (size_t)v * RT_STRIDE;
         double r0, r1;
         if (MODE == 0) {
             double Jp[12], Jc[18], Jx[6];
-            cvxk::reproj_jacobian(in, rt, X0, X1, X2, a.obs_x[o], a.obs_y[o], r0, r1, Jp, Jc, Jx);
+            cvxk::reproj_jacobian(in, rt, X0, X1, X2, ox, oy, r0, r1, Jp, Jc, Jx);
             int q = 0;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(IP_THREADS) k_inner_point(InnerArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc[6 + i] += Jx[i] * r0 + Jx[3 + i] * r1;
         } else {
-            cvxk::reproj_residual(in, rt, X0, X1, X2, a.obs_x[o], a.obs_y[o], r0, r1);
+            cvxk::reproj_residual(in, rt, X0, X1, X2, ox, oy, r0, r1);
         }
         acc[NA - 1] += r0 * r0 + r1 * r1;
     }

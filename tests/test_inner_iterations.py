@@ -72,9 +72,24 @@ def test_ordering_on_the_shapes_where_ceres_rule_is_obvious():
     assert g[-1] == -1 and np.all(g[10:-1] == 2)
 
 
+def test_ordering_rejects_malformed_input():
+    d = cvx_amd.synth_calib(1, 4, 3, 3, 5)
+    ok = (d["cam_of_view"], d["view_off"], d["point_id"], 1, 9)
+    inner_ordering(*ok)
+    bad_off = d["view_off"].copy(); bad_off[2] = bad_off[1] - 1
+    bad_pid = d["point_id"].copy(); bad_pid[3] = 9
+    bad_cam = d["cam_of_view"].copy(); bad_cam[1] = 1
+    for args in ((d["cam_of_view"], bad_off, d["point_id"], 1, 9), (d["cam_of_view"], d["view_off"], bad_pid, 1, 9),
+                 (bad_cam, d["view_off"], d["point_id"], 1, 9)):
+        with pytest.raises(capi.CvxError) as e:
+            inner_ordering(*args)
+        assert e.value.status == 1          # CVX_ERR_INVALID_ARG
+
+
 def test_refine_options_ask_for_inner_iterations():
     o = capi.options("refine")                     # calibration.cpp:424
     assert o.inner_iterations == 1 and o.inner_iteration_tolerance == 1e-3
+    assert capi.options("toolba").inner_iterations == 1       # hand_eye_registration.cpp:205
     assert capi.options("handeye").inner_iterations == 0      # handeye.cpp:315 leaves it commented out
     assert capi.options("levmar").inner_iterations == 0
 
