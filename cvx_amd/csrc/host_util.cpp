@@ -322,7 +322,7 @@ extern "C" int cvx_handeye_pairs_moving(int n, const double *G, const double *Tt
 // ---------------------------------------------------------------------------------------
 extern "C" int cvx_calib_inner_ordering(int C, int V, int P, const int *cam_of_view, const int *view_off,
                                         const int *point_id, int fix_intrinsics, int fix_points, int *group, int *n_sets) {
-    if (C < 1 || V < 0 || P < 1 || !cam_of_view || !view_off || !group || !n_sets) return CVX_ERR_INVALID_ARG;
+    if (C < 1 || V < 0 || P < 1 || (V > 0 && !cam_of_view) || !view_off || !group || !n_sets) return CVX_ERR_INVALID_ARG;
     const int NB = C + P + V;
     if (view_off[0] != 0) return CVX_ERR_INVALID_ARG;
     for (int v = 0; v < V; ++v)

@@ -86,6 +86,41 @@ def test_refine_with_inner_iterations_follows_the_oracle(orc, case):
     g.close()
 
 
+def test_blocks_without_residuals_stay_where_they_are(orc):
+    """A view without markers and a board point nobody sees are in no residual block: Ceres never learns of them,
+    the ordering leaves them out (-1) and a pass must not touch them; a handle without views has nothing to do."""
+    d = cvx_amd.synth_calib(2, 6, 9, 6, 21)
+    view_of = np.repeat(np.arange(d["V"]), np.diff(d["view_off"]))
+    keep = (d["point_id"] != 7) & (view_of != 3)
+    vo = np.concatenate([[0], np.cumsum(np.bincount(view_of[keep], minlength=d["V"]))]).astype(np.int32)
+    args = (d["cam_of_view"], vo, d["point_id"][keep], d["obs_x"][keep], d["obs_y"][keep], 2, 54)
+    g, o = cvx_amd.Calib(*args), orc.Calib(*args)
+    grp, n = o.inner_ordering()
+    assert grp[2 + 7] == -1 and grp[2 + 54 + 3] == -1 and np.sum(grp < 0) == 2
+    x = (d["intr_init"], d["poses_init"], d["points_init"])
+    g.set_params(*x)
+    io, po, xo, co = o.inner_pass(*x)
+    cg = g.inner_pass()
+    ig, pg, xg = g.get_params()
+    assert abs(cg - co) <= 1e-11 * co and rel_err(ig, io) < 1e-11 and rel_err(pg, po) < 1e-10 and rel_err(xg, xo) < 1e-11
+    assert np.array_equal(xg[7], d["points_init"][7]) and np.array_equal(pg[3], d["poses_init"][3])
+    g.set_params(*x)
+    s = g.solve(capi.options("refine"))
+    so = o.solve(*x, orc.options("refine"))[3]
+    assert (s.iterations, s.termination, s.num_inner_iteration_steps) == (so.iterations, so.termination, so.num_inner_iteration_steps)
+    tg, to = s.trace()["cost"], so.trace()["cost"]
+    assert np.all(np.abs(tg - to) <= 1e-9 * to)
+    assert abs(s.final_cost - so.final_cost) <= 1e-10 * so.final_cost
+    ig, pg, xg = g.get_params()
+    assert np.array_equal(xg[7], d["points_init"][7])      # the outer iteration moves an unseen point nowhere either
+    g.close()
+    # no views at all: nothing to minimise over, the pass returns a zero cost
+    e = cvx_amd.Calib(np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0), np.zeros(0), 1, 54)
+    e.set_params(d["intr_init"][:1], np.zeros((0, 6)), d["points_init"])
+    assert e.inner_pass() == 0.0
+    e.close()
+
+
 def test_config4_size_passes(orc):
     """BASELINE config 4 (8 cameras x 1 250 views x 108 corners = 1.08 M observations): the pass at full size through
     properties -- it descends, a second one gains little, each pose block ends where the oracle's LM on that block
