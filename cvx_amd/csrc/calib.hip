@@ -494,7 +494,7 @@ int inner_pass(cvx_calib *h, int which) {
     a.blk_group = h->d_blk_group; a.H = h->d_ib_H; a.st = h->d_ib_st; a.xc = h->d_ib_xc; a.cc = h->d_ib_cc;
     a.flag = h->d_ib_flag; a.cam_slab = h->d_ib_slab; a.active = h->d_ib_active;
     a.pt_slab = h->d_ib_ptslab; a.pt_slices = h->pt_slices;
-    a.C = h->C; a.P = h->P; a.V = h->V; a.ncf = h->ncf; a.fix_k3 = h->fix_k3; a.n_view_groups = h->n_groups;
+    a.C = h->C; a.P = h->P; a.V = h->V; a.ncf = h->ncf; a.fix_k3 = h->fix_k3;
     const dim3 per_block((NB + 63) / 64), t64(64);
     for (int set = 0; set < h->inner_sets; ++set) {
         const int types = h->inner_types[set];

@@ -14,16 +14,18 @@
 // iteration:
 //   lin    normal equations H = J^T J, g = J^T r and the cost over the block's own observations
 //            pose block:   one wave per view (rotation table of the block's pose made in registers)
-//            point block:  workgroups per point, over the point's observation list
-//            camera block: one workgroup per group of views of the camera (K2's groups), then a fixed-order sum
-//            (point blocks likewise when a point's list is long: several workgroups per point)
+//            point block:  pt_slices workgroups per point, each over its share of the point's observation list
+//                          (view, camera and observed corner copied into the list's order: coalesced reads)
+//            camera block: one workgroup per group of views of the camera (K2's groups)
+//            k_inner_sum:  the partial sums of a camera or a point, added in a fixed order
+//            (view-sharded runs: the sums of the shared blocks are all-reduced here, k_inner_xchg)
 //   solve  one thread per block: Jacobi scales (first round), gradient test, damped Cholesky solve with the
 //          invalid-step loop, parameter-tolerance test, candidate block
 //   cost   the candidate's cost over the same observations
 //   decide one thread per block: function-tolerance test, step quality, accept (the block's parameters are
 //          overwritten in place) or reject, radius update; counts the blocks that go on
 // Blocks of a set share no observation, so what one block reads of the others never changes during the set.
-// All sums are taken in a fixed order (no atomics on data).
+// All sums are taken in a fixed order (no atomics on data; the count of running blocks is an atomic sum of ones).
 #pragma once
 #include "calib_kernels.h"
 
@@ -63,7 +65,7 @@ struct InnerArgs {
     double *pt_slab;                         // [points][pt_slices][PT_SLOT]
     int pt_slices;                           // workgroups per point
     double *active;                          // number of blocks that go on after `decide` (a double: it is all-reduced)
-    int C, P, V, ncf, fix_k3, n_view_groups;
+    int C, P, V, ncf, fix_k3;
     int cur;                                 // the set being minimised
 };
 
