@@ -519,6 +519,7 @@ def main():
                        "observations_rank0": N, "views_rank0": V, "shared_unknowns": ns,
                        "parallelism": "views sharded over %d GPU(s), one all-reduce of the reduced system per iteration" % world,
                        "iterations_per_solve": ITERS_PER_SOLVE, "accepted_steps_in_last_solve": last.num_successful,
+                       "inner_iterations": "not in the timed steps (Ceres runs them on a solve's first candidates only, until a pass gains < 1e-3); their cost is in `inner_iterations`",
                        "final_cost_after_%d_iterations" % ITERS_PER_SOLVE: last.final_cost},
             "roofline": roof,
             "iteration": {"flops_per_step_rank0": step_flops, "achieved": step_flops / step_s / 1e12,
