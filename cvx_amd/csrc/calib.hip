@@ -347,15 +347,19 @@ int exchange_sum(cvx_calib *h, double *d, size_t count) {
 int exchange_sum_host(cvx_calib *h, std::vector<double> &v) {
     if (h->nranks <= 1 || v.empty()) return CVX_OK;
     if (!h->xdev) return h->xfn(h->xctx, v.data(), v.size(), 0, nullptr) ? CVX_ERR_EXCHANGE : CVX_OK;
-    double *d = nullptr;
-    int st = dev_alloc(&d, v.size());
-    if (st) return st;
+    // a device-buffer hook: through device memory (the pass's own four doubles when they suffice)
+    const bool small = v.size() <= 4 && h->d_ib_out;
+    double *d = small ? h->d_ib_out : nullptr;
+    if (!small) {
+        int st = dev_alloc(&d, v.size());
+        if (st) return st;
+    }
     hipError_t e = hipMemcpyAsync(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
     int rc = 0;
     if (e == hipSuccess) rc = h->xfn(h->xctx, d, v.size(), 1, (void *)h->stream);
     if (e == hipSuccess && !rc) e = hipMemcpyAsync(v.data(), d, v.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
+    if (!small) (void)hipFree(d);
     if (rc) return CVX_ERR_EXCHANGE;
     CVX_HIP(e);
     return CVX_OK;
@@ -442,9 +446,15 @@ int ensure_inner(cvx_calib *h) {
         for (int v = 0; v < V; ++v)
             for (int o = h->h_view_off[v]; o < h->h_view_off[v + 1]; ++o) view_of[o] = v;
         for (int64_t k = 0; k < h->N; ++k) { pt_view[k] = view_of[pt_obs[k]]; pt_cam[k] = h->h_cam_of_view[pt_view[k]]; }
-        if (h->N) CVX_HIP(hipMemcpy(obs.data(), h->d_obs_x, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost));
+        if (h->N) {
+            CVX_HIP(hipMemcpyAsync(obs.data(), h->d_obs_x, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, s));
+            CVX_HIP(hipStreamSynchronize(s));
+        }
         for (int64_t k = 0; k < h->N; ++k) pt_ox[k] = obs[pt_obs[k]];
-        if (h->N) CVX_HIP(hipMemcpy(obs.data(), h->d_obs_y, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost));
+        if (h->N) {
+            CVX_HIP(hipMemcpyAsync(obs.data(), h->d_obs_y, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, s));
+            CVX_HIP(hipStreamSynchronize(s));
+        }
         for (int64_t k = 0; k < h->N; ++k) pt_oy[k] = obs[pt_obs[k]];
     }
     st = dev_upload(&h->d_pt_off, pt_off.data(), pt_off.size(), s); if (st) return st;
