@@ -22,6 +22,10 @@ CASES = {
     "fixed_intrinsics": dict(spec=(1, 6, 9, 6, 13), ragged=0, fix={"fix_intrinsics": True}),
     "fixed_points": dict(spec=(2, 9, 9, 6, 14), ragged=2, fix={"fix_points": True}),
     "poses_only": dict(spec=(2, 4, 9, 6, 14), ragged=2, fix={"fix_intrinsics": True, "fix_points": True}),
+    # the limits of the build: CVX_MAX_POINTS board points; CVX_MAX_CAMERAS cameras (one view each: cameras and poses
+    # tie in degree, the naming order decides)
+    "max_points": dict(spec=(4, 3, 28, 16, 23), ragged=5, fix={}),
+    "max_cameras": dict(spec=(64, 1, 4, 3, 24), ragged=0, fix={"fix_points": True}),
 }
 
 

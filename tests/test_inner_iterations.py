@@ -20,6 +20,8 @@ SHAPES = [
     (2, 9, 9, 6, 14, 2, True, False),
     (2, 9, 9, 6, 14, 2, False, True),
     (1, 6, 9, 6, 13, 0, True, True),
+    (4, 3, 28, 16, 23, 5, False, False),           # CVX_MAX_POINTS board points
+    (64, 1, 4, 3, 24, 0, False, False),            # CVX_MAX_CAMERAS cameras of one view each: cameras and poses tie in degree
 ]
 
 
