@@ -394,7 +394,10 @@ def main():
             inner = {"in_timed_steps": False, "one_pass_from_start_ms": ms_pass, "cost_before": fs.initial_cost,
                      "cost_after_pass": c_pass, "refine_ms_with": full["ms_total"], "refine_iterations_with": fs.iterations,
                      "refine_ms_without": ms0, "refine_iterations_without": fs0.iterations,
-                     "final_cost_with": fs.final_cost, "final_cost_without": fs0.final_cost}
+                     "final_cost_with": fs.final_cost, "final_cost_without": fs0.final_cost,
+                     # the whole refine with the reference's options, set-up and passes included, in the line's unit
+                     "observation_iterations_per_s_whole_refine_with": d["N"] * fs.iterations / (full["ms_total"] * 1e-3),
+                     "observation_iterations_per_s_whole_refine_without": d["N"] * fs0.iterations / (ms0 * 1e-3)}
 
         # ---- evaluation mode: residuals + Jacobian blocks materialised in HBM (k_eval), hipEvent-timed ----
         g.set_params(intr0, d["poses_init"], pts0)
