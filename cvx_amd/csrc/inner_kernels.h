@@ -246,12 +246,12 @@ __global__ void __launch_bounds__(IC_THREADS) k_inner_cam(InnerArgs a) {
     if (threadIdx.x < NA) a.cam_slab[(size_t)g * IB_STRIDE + (MODE == 0 ? threadIdx.x : IB_COST)] = acc[0];
 }
 
-// the partial sums of a shared block, added in list order (four interleaved running sums, then those in order):
+// the partial sums of a shared block, added in list order (sixteen interleaved running sums, then those in order):
 // workgroup b < C: camera b over its view groups; workgroup C + p: point p over its slices
-constexpr int IS_THREADS = 256;
+constexpr int IS_THREADS = 1024, IS_WAYS = IS_THREADS / 64;
 template <int MODE>
 __global__ void __launch_bounds__(IS_THREADS) k_inner_sum(InnerArgs a) {
-    __shared__ double sh[4][64];
+    __shared__ double sh[IS_WAYS][64];
     const int id = blockIdx.x, k = threadIdx.x & 63, j = threadIdx.x >> 6;
     if (!block_runs(a, id, MODE == 0 ? PH_LIN : PH_CAND)) return;
     const bool cam = id < a.C;
@@ -259,16 +259,20 @@ __global__ void __launch_bounds__(IS_THREADS) k_inner_sum(InnerArgs a) {
     double s = 0.0;
     if (MODE == 0 ? k < nval : k == last) {
         if (cam) {
-            for (int i = a.glist_off[id] + j; i < a.glist_off[id + 1]; i += 4) s += a.cam_slab[(size_t)a.glist[i] * IB_STRIDE + k];
+#pragma unroll 4
+            for (int i = a.glist_off[id] + j; i < a.glist_off[id + 1]; i += IS_WAYS) s += a.cam_slab[(size_t)a.glist[i] * IB_STRIDE + k];
         } else {
             const double *src = a.pt_slab + (size_t)(id - a.C) * a.pt_slices * PT_SLOT;
-            for (int i = j; i < a.pt_slices; i += 4) s += src[(size_t)i * PT_SLOT + k];
+#pragma unroll 4
+            for (int i = j; i < a.pt_slices; i += IS_WAYS) s += src[(size_t)i * PT_SLOT + k];
         }
     }
     sh[j][k] = s;
     __syncthreads();
     if (j != 0 || (MODE == 0 ? k >= nval : k != last)) return;
-    const double t = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < IS_WAYS; ++w) t += sh[w][k];
     if (MODE == 1) { a.cc[id] = 0.5 * t; return; }
     const int dst = cam ? k : (k < 6 ? k : k < 9 ? IB_G + (k - 6) : IB_COST);
     a.H[(size_t)id * IB_STRIDE + dst] = k == last ? 0.5 * t : t;
