@@ -543,6 +543,10 @@ int inner_pass(cvx_calib *h, int which) {
             }
             hipLaunchKernelGGL(cvxi::k_inner_decide, per_block, t64, 0, h->stream, a);
             CVX_HIP(hipGetLastError());
+            // No set is through after one round but by accident (every block at a tolerance at once): the count is
+            // not read then -- a round in which nothing runs costs less than the host's wait for the number.  (The same
+            // on every rank: `round` is.)
+            if (round == 0) continue;
             if (shared && sharded) {        // leave the set together (a set of pose blocks only has nothing to agree on)
                 st = exchange_sum(h, h->d_ib_active, 1);
                 if (st) return st;
