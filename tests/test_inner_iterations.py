@@ -65,6 +65,12 @@ def test_ordering_on_the_shapes_where_ceres_rule_is_obvious():
     d = cvx_amd.synth_calib(1, 200, 3, 3, 5)
     g, n = inner_ordering(d["cam_of_view"], d["view_off"], d["point_id"], 1, 9)
     assert n == 3 and g[0] == 0 and np.all(g[1:10] == 1) and np.all(g[10:] == 2)
+    # BASELINE config 4 (10 000 views of 108 points, 8 cameras): pose 109 < point 10 008 < camera 1 358 + ...: the
+    # poses go first, then the points (degree 8 once the poses are gone, the cameras have 108), then the cameras;
+    # reversed: cameras, points, poses
+    d4 = cvx_amd.synth_calib(8, 1250, 12, 9, 20260004)
+    g4, n4 = inner_ordering(d4["cam_of_view"], d4["view_off"], d4["point_id"], 8, 108)
+    assert n4 == 3 and np.all(g4[:8] == 0) and np.all(g4[8:116] == 1) and np.all(g4[116:] == 2)
     # nothing shared is free: every pose stands alone, one set
     g, n = inner_ordering(d["cam_of_view"], d["view_off"], d["point_id"], 1, 9, True, True)
     assert n == 1 and g[0] == -1 and np.all(g[1:10] == -1) and np.all(g[10:] == 0)
