@@ -88,6 +88,16 @@ def test_edge_cases():
     p, s = g.solve(x0)
     assert s.termination == 1 and np.array_equal(p, x0)
     g.close()
+    # inner iterations are a matter of several parameter blocks; solveNonLinear has one (handeye.cpp:315 leaves the
+    # option off): asked for, the solve refuses at its first candidate rather than ignore the request
+    G, T, xg, xs = cvx_amd.synth_handeye(20, 3)
+    A, B = cvx_amd.handeye_pairs(G, T)
+    g = cvx_amd.HandEye(*cvx_amd.pairs_to_quat_trans(A, B))
+    oi = capi.options("handeye"); oi.inner_iterations = 1
+    with pytest.raises(capi.CvxError) as e:
+        g.solve(xs, oi)
+    assert e.value.status == 4          # CVX_ERR_UNSUPPORTED
+    g.close()
     # one pair, and a pair count that is not a multiple of the wave / block size
     from oracle import oracle as orc
     rng = np.random.default_rng(5)
