@@ -102,6 +102,44 @@ def test_refine_options_ask_for_inner_iterations():
     assert capi.options("levmar").inner_iterations == 0
 
 
+def test_oracle_pass_is_block_coordinate_descent_in_the_order_of_the_sets(orc):
+    """An independent statement of what a pass is: set after set, every block of the set moved to the minimum of the
+    cost over that block alone (scipy's MINPACK LM to convergence, on the oracle's residuals).  The oracle's blocks
+    stop at Ceres' function tolerance of 1e-6, so the two agree to that order, not to rounding -- which is enough to
+    tell a wrong order of the sets, a block left out, or a block minimised over the wrong residuals."""
+    from scipy.optimize import least_squares
+    d = cvx_amd.synth_calib(2, 5, 4, 3, 41, ragged=5)
+    C_, P, V = d["C"], d["P"], d["V"]
+    o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], C_, P)
+    group, n = o.inner_ordering()
+    x = [d["intr_init"].copy(), d["poses_init"].copy(), d["points_init"].copy()]
+    free_intr = [0, 1, 2, 3, 4, 5, 7, 8]                    # k3 is held (calibration.cpp:410-415)
+
+    def residuals():
+        return o.eval(*x)[0].ravel()
+    for s in range(n):
+        for b in np.nonzero(group == s)[0]:
+            if b < C_:
+                arr, idx = x[0][b], free_intr
+            elif b < C_ + P:
+                arr, idx = x[2][b - C_], [0, 1, 2]
+            else:
+                arr, idx = x[1][b - C_ - P], list(range(6))
+
+            def f(z, arr=arr, idx=idx):
+                arr[idx] = z
+                return residuals()
+            z = least_squares(f, arr[idx].copy(), method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14).x
+            arr[idx] = z
+    exact = o.cost(*x)
+    io, po, xo, co = o.inner_pass(d["intr_init"], d["poses_init"], d["points_init"])
+    c0 = o.cost(d["intr_init"], d["poses_init"], d["points_init"])
+    assert exact < 0.1 * c0
+    assert exact <= co * (1 + 1e-9) and co - exact <= 2e-3 * exact     # the oracle stops a little short of each minimum
+    assert np.max(np.abs(io - x[0]) / np.maximum(np.abs(x[0]), 1e-2)) < 5e-2
+    assert np.max(np.abs(xo - x[2])) < 5e-2 * 25.0 and np.max(np.abs(po - x[1])) < 5e-2 * np.max(np.abs(x[1]))
+
+
 def test_oracle_pass_descends_and_the_solve_ends_where_the_plain_one_does(orc):
     d = cvx_amd.synth_calib(2, 7, 12, 9, 11, ragged=4)
     o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 2, 108)
