@@ -58,7 +58,7 @@ struct cvx_calib {
     bool aligned = false;   // every group's views list the same points in the same order
     size_t k2_lds = 0;
     int n_groups = 0, n_chunks = 0, n_cost_blocks = 0;
-    std::vector<int> h_cam_of_view, h_view_off;
+    std::vector<int> h_cam_of_view, h_view_off, h_point_id;
     // device: static
     int *d_view_off = nullptr, *d_cam_of_view = nullptr, *d_point_id = nullptr, *d_view_id = nullptr;
     bool A_ready = false;            // the last linearisation wrote the damped matrix A itself (one rank)
@@ -95,6 +95,8 @@ struct cvx_calib {
     bool inner_ready = false;
     int inner_sets = 0;
     std::vector<int> inner_types;    // per set: bit t set when the set holds blocks of type t (camera, point, pose)
+    int *d_ib_iblock = nullptr;      // one allocation each for the integers and the doubles below
+    double *d_ib_dblock = nullptr;
     int *d_pt_off = nullptr, *d_pt_obs = nullptr, *d_blk_group = nullptr, *d_ib_flag = nullptr;
     double *d_ib_active = nullptr, *d_ib_X = nullptr;   // blocks that go on; exchange buffer of the shared blocks' sums
     std::vector<double> x_stage;     // host staging of an exchange over a host-buffer hook
@@ -124,9 +126,7 @@ cvx_calib::~cvx_calib() {
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
                     d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
-                    d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_pt_off, d_pt_obs, d_blk_group,
-                    d_ib_flag, d_ib_active, d_ib_H, d_ib_st, d_ib_xc, d_ib_cc, d_ib_slab, d_ib_out, d_ib_ptslab, d_ib_X, d_pt_ox, d_pt_oy,
-                    d_pt_view, d_pt_cam};
+                    d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
@@ -366,14 +366,23 @@ int exchange_sum_host(cvx_calib *h, std::vector<double> &v) {
 }
 
 void free_inner(cvx_calib *h) {
-    void *ptrs[] = {h->d_pt_off, h->d_pt_obs, h->d_blk_group, h->d_ib_flag, h->d_ib_active, h->d_ib_H, h->d_ib_st, h->d_ib_xc,
-                    h->d_ib_cc, h->d_ib_slab, h->d_ib_out, h->d_ib_ptslab, h->d_ib_X, h->d_pt_ox, h->d_pt_oy, h->d_pt_view, h->d_pt_cam};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
-    h->d_pt_ox = h->d_pt_oy = nullptr; h->d_pt_view = h->d_pt_cam = nullptr;
-    h->d_pt_off = h->d_pt_obs = h->d_blk_group = h->d_ib_flag = nullptr;
+    if (h->d_ib_iblock) (void)hipFree(h->d_ib_iblock);
+    if (h->d_ib_dblock) (void)hipFree(h->d_ib_dblock);
+    h->d_ib_iblock = nullptr; h->d_ib_dblock = nullptr;
+    h->d_pt_off = h->d_pt_obs = h->d_blk_group = h->d_ib_flag = h->d_pt_view = h->d_pt_cam = nullptr;
     h->d_ib_active = h->d_ib_H = h->d_ib_st = h->d_ib_xc = h->d_ib_cc = h->d_ib_slab = h->d_ib_out = h->d_ib_ptslab = h->d_ib_X = nullptr;
+    h->d_pt_ox = h->d_pt_oy = nullptr;
     h->inner_ready = false;
+}
+
+// what a point block reads per observation, laid out in the order of its list
+__global__ void k_inner_gather(const int *__restrict__ pt_obs, const int *__restrict__ view_id, const int *__restrict__ cam_of_view,
+                               const double *__restrict__ obs_x, const double *__restrict__ obs_y, long long n,
+                               int *__restrict__ pt_view, int *__restrict__ pt_cam, double *__restrict__ pt_ox, double *__restrict__ pt_oy) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int o = pt_obs[k], v = view_id[o];
+    pt_view[k] = v; pt_cam[k] = cam_of_view[v]; pt_ox[k] = obs_x[o]; pt_oy[k] = obs_y[o];
 }
 
 // ---- inner iterations (calibration.cpp:424): ordering, per-point observation lists and block state, on first use.
@@ -385,9 +394,7 @@ int ensure_inner(cvx_calib *h) {
     if (h->inner_ready) return CVX_OK;
     free_inner(h);
     const int C = h->C, P = h->P, V = h->V, NB = C + P + V;
-    std::vector<int> point_id((size_t)h->N);
-    if (h->N) CVX_HIP(hipMemcpyAsync(point_id.data(), h->d_point_id, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
-    CVX_HIP(hipStreamSynchronize(h->stream));
+    const std::vector<int> &point_id = h->h_point_id;
     std::vector<int> group(NB);
     int st;
     if (h->nranks > 1) {
@@ -438,44 +445,38 @@ int ensure_inner(cvx_calib *h) {
         for (int64_t o = 0; o < h->N; ++o) pt_obs[pos[point_id[o]]++] = (int)o;      // ascending observation = ascending view
     }
     hipStream_t s = h->stream;
-    // what a point block reads per observation, laid out in the order of its list
-    std::vector<int> pt_view((size_t)h->N), pt_cam((size_t)h->N);
-    std::vector<double> pt_ox((size_t)h->N), pt_oy((size_t)h->N), obs((size_t)h->N);
-    {
-        std::vector<int> view_of((size_t)h->N);
-        for (int v = 0; v < V; ++v)
-            for (int o = h->h_view_off[v]; o < h->h_view_off[v + 1]; ++o) view_of[o] = v;
-        for (int64_t k = 0; k < h->N; ++k) { pt_view[k] = view_of[pt_obs[k]]; pt_cam[k] = h->h_cam_of_view[pt_view[k]]; }
-        if (h->N) {
-            CVX_HIP(hipMemcpyAsync(obs.data(), h->d_obs_x, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, s));
-            CVX_HIP(hipStreamSynchronize(s));
-        }
-        for (int64_t k = 0; k < h->N; ++k) pt_ox[k] = obs[pt_obs[k]];
-        if (h->N) {
-            CVX_HIP(hipMemcpyAsync(obs.data(), h->d_obs_y, sizeof(double) * (size_t)h->N, hipMemcpyDeviceToHost, s));
-            CVX_HIP(hipStreamSynchronize(s));
-        }
-        for (int64_t k = 0; k < h->N; ++k) pt_oy[k] = obs[pt_obs[k]];
-    }
-    st = dev_upload(&h->d_pt_off, pt_off.data(), pt_off.size(), s); if (st) return st;
-    st = dev_upload(&h->d_pt_obs, pt_obs.data(), pt_obs.size(), s); if (st) return st;
-    st = dev_upload(&h->d_pt_view, pt_view.data(), pt_view.size(), s); if (st) return st;
-    st = dev_upload(&h->d_pt_cam, pt_cam.data(), pt_cam.size(), s); if (st) return st;
-    st = dev_upload(&h->d_pt_ox, pt_ox.data(), pt_ox.size(), s); if (st) return st;
-    st = dev_upload(&h->d_pt_oy, pt_oy.data(), pt_oy.size(), s); if (st) return st;
-    st = dev_upload(&h->d_blk_group, group.data(), group.size(), s); if (st) return st;
-    st = dev_alloc(&h->d_ib_flag, 4 * (size_t)NB); if (st) return st;
-    st = dev_alloc(&h->d_ib_active, 1); if (st) return st;
-    st = dev_alloc(&h->d_ib_H, (size_t)NB * cvxi::IB_STRIDE); if (st) return st;
-    st = dev_alloc(&h->d_ib_st, (size_t)NB * cvxi::IB_STATE); if (st) return st;
-    st = dev_alloc(&h->d_ib_xc, 9 * (size_t)NB); if (st) return st;
-    st = dev_alloc(&h->d_ib_cc, (size_t)NB); if (st) return st;
-    st = dev_alloc(&h->d_ib_slab, (size_t)std::max(1, h->n_groups) * cvxi::IB_STRIDE); if (st) return st;
-    st = dev_alloc(&h->d_ib_out, 4); if (st) return st;
-    st = dev_alloc(&h->d_ib_X, (size_t)(C + P) * cvxi::IB_STRIDE); if (st) return st;
     // a point's list is cut so that a workgroup of 256 lanes sees about two observations per lane
     h->pt_slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, h->N / P / 512));
-    st = dev_alloc(&h->d_ib_ptslab, (size_t)P * h->pt_slices * cvxi::PT_SLOT); if (st) return st;
+    // two allocations, carved in 256-byte steps
+    const size_t N = (size_t)h->N;
+    auto up = [](size_t n, size_t unit) { return (n + unit - 1) / unit * unit; };
+    const size_t i_sizes[] = {(size_t)P + 1, N, N, N, (size_t)NB, 4 * (size_t)NB};
+    const size_t d_sizes[] = {8, (size_t)NB * cvxi::IB_STRIDE, (size_t)NB * cvxi::IB_STATE, 9 * (size_t)NB, (size_t)NB,
+                              (size_t)std::max(1, h->n_groups) * cvxi::IB_STRIDE, (size_t)(C + P) * cvxi::IB_STRIDE,
+                              (size_t)P * h->pt_slices * cvxi::PT_SLOT, N, N};
+    size_t i_tot = 0, d_tot = 0;
+    for (size_t n : i_sizes) i_tot += up(std::max<size_t>(n, 1), 64);
+    for (size_t n : d_sizes) d_tot += up(std::max<size_t>(n, 1), 32);
+    st = dev_alloc(&h->d_ib_iblock, i_tot); if (st) return st;
+    st = dev_alloc(&h->d_ib_dblock, d_tot); if (st) return st;
+    {
+        int *ip = h->d_ib_iblock;
+        int **iv[] = {&h->d_pt_off, &h->d_pt_obs, &h->d_pt_view, &h->d_pt_cam, &h->d_blk_group, &h->d_ib_flag};
+        for (int k = 0; k < 6; ++k) { *iv[k] = ip; ip += up(std::max<size_t>(i_sizes[k], 1), 64); }
+        double *dp = h->d_ib_dblock;
+        double **dv[] = {&h->d_ib_active, &h->d_ib_H, &h->d_ib_st, &h->d_ib_xc, &h->d_ib_cc, &h->d_ib_slab, &h->d_ib_X,
+                         &h->d_ib_ptslab, &h->d_pt_ox, &h->d_pt_oy};
+        for (int k = 0; k < 10; ++k) { *dv[k] = dp; dp += up(std::max<size_t>(d_sizes[k], 1), 32); }
+        h->d_ib_out = h->d_ib_active + 4;       // the first eight doubles: running count | pad | four of the pass's own
+    }
+    CVX_HIP(hipMemcpyAsync(h->d_pt_off, pt_off.data(), pt_off.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    if (N) CVX_HIP(hipMemcpyAsync(h->d_pt_obs, pt_obs.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
+    CVX_HIP(hipMemcpyAsync(h->d_blk_group, group.data(), group.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    if (N) {
+        hipLaunchKernelGGL(k_inner_gather, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, h->d_pt_obs, h->d_view_id,
+                           h->d_cam_of_view, h->d_obs_x, h->d_obs_y, (long long)N, h->d_pt_view, h->d_pt_cam, h->d_pt_ox, h->d_pt_oy);
+        CVX_HIP(hipGetLastError());
+    }
     CVX_HIP(hipMemsetAsync(h->d_ib_flag, 0, 4 * (size_t)NB * sizeof(int), s));
     CVX_HIP(hipMemsetAsync(h->d_ib_st, 0, (size_t)NB * cvxi::IB_STATE * sizeof(double), s));
     if (!h->h_ib_active) CVX_HIP(hipHostMalloc((void **)&h->h_ib_active, 4 * sizeof(double), hipHostMallocDefault));
@@ -884,6 +885,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     const int W = h->T / 64;
     h->h_cam_of_view.assign(d->cam_of_view, d->cam_of_view + V);
     h->h_view_off.assign(d->view_off, d->view_off + V + 1);
+    if (d->n_obs) h->h_point_id.assign(d->point_id, d->point_id + d->n_obs);
 
     // groups (K2 workgroups) and chunks (K3 row ranges): contiguous views of one camera
     std::vector<int> grp_v0, grp_cam, chk_row0, chk_cam;

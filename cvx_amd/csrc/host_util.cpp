@@ -329,48 +329,53 @@ extern "C" int cvx_calib_inner_ordering(int C, int V, int P, const int *cam_of_v
         if (view_off[v + 1] < view_off[v]) return CVX_ERR_INVALID_ARG;
     const int64_t N = view_off[V];
     if (N > 0 && !point_id) return CVX_ERR_INVALID_ARG;
-    // observations by point; which camera sees which point; the views of a camera
+    // One pass over the observations: how often each point is seen, which camera sees which point, the views of a
+    // camera, and the rank of every block = the order in which refine's loop first names it (intrinsics, pose, point
+    // per marker).  The lists of a point's views are made only if a point ever has to name its poses (below).
     std::vector<int64_t> pt_off((size_t)P + 1, 0);
-    for (int64_t o = 0; o < N; ++o) {
-        if (point_id[o] < 0 || point_id[o] >= P) return CVX_ERR_INVALID_ARG;
-        pt_off[point_id[o] + 1]++;
-    }
-    for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
-    std::vector<int> pt_view((size_t)N);
     std::vector<char> sees((size_t)C * P, 0);
     std::vector<std::vector<int>> cam_views(C);
-    {
-        std::vector<int64_t> pos(pt_off.begin(), pt_off.end() - 1);
-        for (int v = 0; v < V; ++v) {
-            const int c = cam_of_view[v];
-            if (c < 0 || c >= C) return CVX_ERR_INVALID_ARG;
-            if (view_off[v + 1] > view_off[v]) cam_views[c].push_back(v);
-            for (int o = view_off[v]; o < view_off[v + 1]; ++o) { pt_view[pos[point_id[o]]++] = v; sees[(size_t)c * P + point_id[o]] = 1; }
-        }
-    }
-    // rank: the order in which refine's loop first names the blocks (intrinsics, pose, point per marker)
     std::vector<int> rank(NB, -1);
     std::vector<char> present(NB, 0);
     int nr = 0, left = 0;
-    for (int v = 0; v < V; ++v)
+    for (int v = 0; v < V; ++v) {
+        const int c = cam_of_view[v];
+        if (c < 0 || c >= C) return CVX_ERR_INVALID_ARG;
+        if (view_off[v + 1] == view_off[v]) continue;
+        cam_views[c].push_back(v);
+        if (!fix_intrinsics && rank[c] < 0) { rank[c] = nr++; present[c] = 1; ++left; }
+        rank[C + P + v] = nr++; present[C + P + v] = 1; ++left;
+        char *sc = sees.data() + (size_t)c * P;
         for (int o = view_off[v]; o < view_off[v + 1]; ++o) {
-            const int ids[3] = {cam_of_view[v], C + P + v, C + point_id[o]};
-            const bool is_free[3] = {!fix_intrinsics, true, !fix_points};
-            for (int k = 0; k < 3; ++k)
-                if (is_free[k] && rank[ids[k]] < 0) { rank[ids[k]] = nr++; present[ids[k]] = 1; ++left; }
+            const int p = point_id[o];
+            if (p < 0 || p >= P) return CVX_ERR_INVALID_ARG;
+            pt_off[p + 1]++;
+            sc[p] = 1;
+            if (!fix_points && rank[C + p] < 0) { rank[C + p] = nr++; present[C + p] = 1; ++left; }
         }
-    auto for_neighbours = [&](int id, auto &&f) {
+    }
+    for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
+    std::vector<int> pt_view;
+    auto need_pt_view = [&]() {
+        if (!pt_view.empty() || N == 0) return;
+        pt_view.resize((size_t)N);
+        std::vector<int64_t> pos(pt_off.begin(), pt_off.end() - 1);
+        for (int v = 0; v < V; ++v)
+            for (int o = view_off[v]; o < view_off[v + 1]; ++o) pt_view[pos[point_id[o]]++] = v;
+    };
+    // f(neighbour) for the neighbours of kind k (0 cameras, 1 points, 2 poses) of vertex id
+    auto for_neighbours = [&](int id, int k, auto &&f) {
         if (id < C) {
-            for (int v : cam_views[id]) f(C + P + v);
-            for (int p = 0; p < P; ++p) if (sees[(size_t)id * P + p]) f(C + p);
+            if (k == 2) for (int v : cam_views[id]) f(C + P + v);
+            if (k == 1) for (int p = 0; p < P; ++p) if (sees[(size_t)id * P + p]) f(C + p);
         } else if (id < C + P) {
             const int p = id - C;
-            for (int64_t k = pt_off[p]; k < pt_off[p + 1]; ++k) f(C + P + pt_view[k]);
-            for (int c = 0; c < C; ++c) if (sees[(size_t)c * P + p]) f(c);
+            if (k == 2) { need_pt_view(); for (int64_t j = pt_off[p]; j < pt_off[p + 1]; ++j) f(C + P + pt_view[j]); }
+            if (k == 0) for (int c = 0; c < C; ++c) if (sees[(size_t)c * P + p]) f(c);
         } else {
             const int v = id - C - P;
-            f(cam_of_view[v]);
-            for (int o = view_off[v]; o < view_off[v + 1]; ++o) f(C + point_id[o]);
+            if (k == 0) f(cam_of_view[v]);
+            if (k == 1) for (int o = view_off[v]; o < view_off[v + 1]; ++o) f(C + point_id[o]);
         }
     };
     std::vector<int> round(NB, -1);
@@ -378,22 +383,56 @@ extern "C" int cvx_calib_inner_ordering(int C, int V, int P, const int *cam_of_v
     std::vector<Vert> q;
     std::vector<char> color(NB);
     int rounds = 0;
+    // A vertex's degree is the number of its neighbours still there.  Whole kinds of blocks come and go together in
+    // the usual shapes, so the count over one kind of neighbour is taken from the lists only while that kind is partly
+    // gone: all there -> the full count, made once; none there -> zero.
+    int there[3] = {0, 0, 0}, at_start[3];          // cameras, points, poses
+    auto kind = [&](int id) { return id < C ? 0 : id < C + P ? 1 : 2; };
+    for (int i = 0; i < NB; ++i) there[kind(i)] += present[i];
+    for (int k = 0; k < 3; ++k) at_start[k] = there[k];
+    std::vector<int> full_a(NB, 0), full_b(NB, 0);  // camera: views, points; point: poses, cameras; pose: camera, points
+    for (int c = 0; c < C; ++c) {
+        full_a[c] = (int)cam_views[c].size();
+        for (int p = 0; p < P; ++p) full_b[c] += sees[(size_t)c * P + p] && present[C + p];
+    }
+    for (int p = 0; p < P; ++p) {
+        full_a[C + p] = (int)(pt_off[p + 1] - pt_off[p]);
+        for (int c = 0; c < C; ++c) full_b[C + p] += sees[(size_t)c * P + p] && present[c];
+    }
+    for (int v = 0; v < V; ++v) {
+        full_a[C + P + v] = present[cam_of_view[v]];
+        full_b[C + P + v] = fix_points ? 0 : view_off[v + 1] - view_off[v];
+    }
+    auto count_kind = [&](int id, int k, int full) {        // neighbours of `id` of kind k that are still there
+        if (there[k] == 0) return 0;
+        if (there[k] == at_start[k]) return full;
+        int d = 0;
+        for_neighbours(id, k, [&](int n) { d += present[n]; });
+        return d;
+    };
     while (left > 0) {
         q.clear();
         for (int i = 0; i < NB; ++i) {
             if (!present[i]) continue;
-            int d = 0;
-            for_neighbours(i, [&](int n) { d += present[n]; });
+            int d;
+            if (i < C) d = count_kind(i, 2, full_a[i]) + count_kind(i, 1, full_b[i]);
+            else if (i < C + P) d = count_kind(i, 2, full_a[i]) + count_kind(i, 0, full_b[i]);
+            else d = count_kind(i, 0, full_a[i]) + count_kind(i, 1, full_b[i]);
             q.push_back({d, rank[i], i});
             color[i] = 0;
         }
         std::sort(q.begin(), q.end(), [](const Vert &a, const Vert &b) { return a.deg != b.deg ? a.deg < b.deg : a.rank < b.rank; });
+        // greedy pass; white[k] = vertices of kind k that can still be taken or greyed: once a kind has none left
+        // (after the first few poses of a dense problem every point and camera is grey) its lists are not walked
+        int white[3] = {there[0], there[1], there[2]};
         for (const Vert &x : q) {
             if (color[x.id]) continue;
-            color[x.id] = 2; round[x.id] = rounds;
-            for_neighbours(x.id, [&](int n) { if (present[n] && !color[n]) color[n] = 1; });
+            color[x.id] = 2; round[x.id] = rounds; --white[kind(x.id)];
+            for (int k = 0; k < 3; ++k)
+                if (k != kind(x.id) && white[k] > 0)
+                    for_neighbours(x.id, k, [&](int n) { if (present[n] && !color[n]) { color[n] = 1; --white[k]; } });
         }
-        for (const Vert &x : q) if (color[x.id] == 2) { present[x.id] = 0; --left; }
+        for (const Vert &x : q) if (color[x.id] == 2) { present[x.id] = 0; --left; --there[kind(x.id)]; }
         ++rounds;
     }
     for (int i = 0; i < NB; ++i) group[i] = round[i] < 0 ? -1 : rounds - 1 - round[i];      // CreateOrdering reverses
