@@ -80,6 +80,26 @@ def test_ordering_on_the_shapes_where_ceres_rule_is_obvious():
     assert g[-1] == -1 and np.all(g[10:-1] == 2)
 
 
+def test_ordering_matches_the_oracle_on_random_shapes(orc):
+    """120 small random problems (1-4 cameras, ragged views, fixed blocks): the library's ordering (stored degrees, lazy
+    lists, early-out greedy pass) equals the oracle's explicit-graph one; some of them have sets that mix kinds."""
+    rng = np.random.default_rng(0)
+    mixed = 0
+    for _ in range(120):
+        C_, VP, bw, bh = int(rng.integers(1, 5)), int(rng.integers(1, 30)), int(rng.integers(2, 7)), int(rng.integers(2, 6))
+        rag = int(rng.choice([0, 2, 3, 6]))
+        fi, fp = bool(rng.uniform() < 0.15), bool(rng.uniform() < 0.3)
+        d = cvx_amd.synth_calib(C_, VP, bw, bh, int(rng.integers(1, 10 ** 6)), ragged=rag)
+        P = bw * bh
+        g, n = inner_ordering(d["cam_of_view"], d["view_off"], d["point_id"], C_, P, fi, fp)
+        o = orc.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], C_, P, fix_intrinsics=fi, fix_points=fp)
+        go, no = o.inner_ordering()
+        assert n == no and np.array_equal(g, go)
+        kind = np.where(np.arange(len(g)) < C_, 0, np.where(np.arange(len(g)) < C_ + P, 1, 2))
+        mixed += any(len(set(kind[g == s])) > 1 for s in range(n))
+    assert mixed >= 1
+
+
 def test_ordering_rejects_malformed_input():
     d = cvx_amd.synth_calib(1, 4, 3, 3, 5)
     ok = (d["cam_of_view"], d["view_off"], d["point_id"], 1, 9)
