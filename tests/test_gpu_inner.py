@@ -90,6 +90,29 @@ def test_refine_with_inner_iterations_follows_the_oracle(orc, case):
     g.close()
 
 
+def test_passes_on_random_shapes(orc):
+    """Thirty small random problems (1-4 cameras, ragged views down to near-empty ones, fixed blocks, free k3): the
+    sets differ from problem to problem (some mix poses and points) and every block runs its own LM."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for _ in range(30):
+        C_, VP, bw, bh = int(rng.integers(1, 5)), int(rng.integers(3, 25)), int(rng.integers(3, 8)), int(rng.integers(3, 6))
+        rag = int(rng.choice([0, 2, 3, 6]))
+        fix = {"fix_intrinsics": bool(rng.uniform() < 0.15), "fix_points": bool(rng.uniform() < 0.3), "fix_k3": bool(rng.uniform() < 0.7)}
+        d = cvx_amd.synth_calib(C_, VP, bw, bh, int(rng.integers(1, 10 ** 6)), ragged=rag)
+        args = (d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], C_, bw * bh)
+        g, o = cvx_amd.Calib(*args, **fix), orc.Calib(*args, **fix)
+        x = (d["intr_init"], d["poses_init"], d["points_init"])
+        g.set_params(*x)
+        io, po, xo, co = o.inner_pass(*x)
+        cg = g.inner_pass()
+        ig, pg, xg = g.get_params()
+        g.close()
+        assert abs(cg - co) <= 1e-9 * co
+        worst = max(worst, rel_err(ig, io), rel_err(pg, po), rel_err(xg, xo))
+    assert worst < 1e-8
+
+
 def test_blocks_without_residuals_stay_where_they_are(orc):
     """A view without markers and a board point nobody sees are in no residual block: Ceres never learns of them,
     the ordering leaves them out (-1) and a pass must not touch them; a handle without views has nothing to do."""
