@@ -71,9 +71,24 @@ struct InnerArgs {
 
 __device__ __forceinline__ int tri(int n, int a, int b) { return a * n - a * (a - 1) / 2 + (b - a); }   // a <= b
 
+// Sum over the wave, valid on WAVE_SUM_LANE (and its whole row of 16).  Data-parallel-primitive moves instead of
+// ds_bpermute shuffles: lane ^ 1, lane ^ 2 inside a quad, the mirrored half row, the mirrored row, then lane 15 of
+// rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 / 3 (masked-off rows add zero).  A fixed order like any other.
+constexpr int WAVE_SUM_LANE = 63;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v += dpp_take<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v);       // row_half_mirror
+    v += dpp_take<0x140, 0xF>(v);       // row_mirror
+    v += dpp_take<0x142, 0xA>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xC>(v);       // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -83,7 +98,7 @@ __device__ __forceinline__ double group_sum(double v, double *sh) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
-    if (lane == 0) sh[wave] = v;
+    if (lane == WAVE_SUM_LANE) sh[wave] = v;
     __syncthreads();
     double t = 0.0;
     if (threadIdx.x == 0)
@@ -98,7 +113,7 @@ __device__ __forceinline__ void group_sum_n(double (&acc)[N], double *sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = wave_sum(acc[i]);
-    if (lane == 0) {
+    if (lane == WAVE_SUM_LANE) {
 #pragma unroll
         for (int i = 0; i < N; ++i) sh[wave * N + i] = acc[i];
     }
@@ -151,7 +166,7 @@ __global__ void __launch_bounds__(256) k_inner_pose(InnerArgs a) {        // (he
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < 28; ++i) acc[i] = wave_sum(acc[i]);
-        if (lane == 0) {
+        if (lane == WAVE_SUM_LANE) {
             double *H = a.H + (size_t)id * IB_STRIDE;
             for (int i = 0; i < 21; ++i) H[i] = acc[i];
             for (int i = 0; i < 6; ++i) H[IB_G + i] = acc[21 + i];
@@ -159,7 +174,7 @@ __global__ void __launch_bounds__(256) k_inner_pose(InnerArgs a) {        // (he
         }
     } else {
         const double c = wave_sum(acc[27]);
-        if (lane == 0) a.cc[id] = 0.5 * c;
+        if (lane == WAVE_SUM_LANE) a.cc[id] = 0.5 * c;
     }
 }
 
