@@ -23,6 +23,17 @@ constexpr int RT_STRIDE = 40;    // per view: R[9] | dR/dw_j [3][9] | t[3] | pad
 constexpr int PT_ACC = 36;       // per point accumulators: Ucx[9][3] | Uxx[6] | gx[3]
 constexpr int AROW = 17;         // LDS stride (doubles) of one staged Jacobian row: odd, so that the 64 lanes' row writes spread over all banks
 
+// Accumulations of K2 (point blocks, 6x6 factor, substitutions) use fused multiply-adds.  -DCVX_NO_CONTRACT is the
+// development build of the rounding-source experiment (scripts/build_nocontract.sh): the same
+// sums as separate multiply and add, which is how a build with -ffp-contract=off rounds them.
+#ifdef CVX_NO_CONTRACT
+#define CVX_ACC_CONTRACT _Pragma("clang fp contract(off)")
+__device__ __forceinline__ double acc_fma(double x, double y, double z) { return x * y + z; }
+#else
+#define CVX_ACC_CONTRACT _Pragma("clang fp contract(fast)")
+__device__ __forceinline__ double acc_fma(double x, double y, double z) { return fma(x, y, z); }
+#endif
+
 // -----------------------------------------------------------------------------------------
 // K0: per-view rotation matrix and its derivative w.r.t. the global angle-axis vector
 // (both branches of ceres::AngleAxisRotatePoint, used at calibration.cpp:286)
@@ -300,7 +311,7 @@ __global__ void __launch_bounds__(256) k_cost(const int *__restrict__ view_id, c
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 
 __device__ __forceinline__ bool chol6_factor(double (&A)[21]) {
-#pragma clang fp contract(fast)
+CVX_ACC_CONTRACT
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -327,7 +338,7 @@ __device__ __forceinline__ bool chol6_factor(double (&A)[21]) {
 
 // z = L^-1 w with the packed factor of chol6_factor
 __device__ __forceinline__ void chol6_forward(const double (&Lf)[21], double (&w)[6]) {
-#pragma clang fp contract(fast)
+CVX_ACC_CONTRACT
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double t = w[i];
@@ -436,17 +447,17 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) pa[c * 3 + b] = fma(Jc[9 + c], Jx[3 + b], fma(Jc[c], Jx[b], pa[c * 3 + b]));
+                    for (int b = 0; b < 3; ++b) pa[c * 3 + b] = acc_fma(Jc[9 + c], Jx[3 + b], acc_fma(Jc[c], Jx[b], pa[c * 3 + b]));
             }
-            pa[27] = fma(Jx[3], Jx[3], fma(Jx[0], Jx[0], pa[27]));
-            pa[28] = fma(Jx[3], Jx[4], fma(Jx[0], Jx[1], pa[28]));
-            pa[29] = fma(Jx[3], Jx[5], fma(Jx[0], Jx[2], pa[29]));
-            pa[30] = fma(Jx[4], Jx[4], fma(Jx[1], Jx[1], pa[30]));
-            pa[31] = fma(Jx[4], Jx[5], fma(Jx[1], Jx[2], pa[31]));
-            pa[32] = fma(Jx[5], Jx[5], fma(Jx[2], Jx[2], pa[32]));
-            pa[33] = fma(Jx[3], r[1], fma(Jx[0], r[0], pa[33]));
-            pa[34] = fma(Jx[4], r[1], fma(Jx[1], r[0], pa[34]));
-            pa[35] = fma(Jx[5], r[1], fma(Jx[2], r[0], pa[35]));
+            pa[27] = acc_fma(Jx[3], Jx[3], acc_fma(Jx[0], Jx[0], pa[27]));
+            pa[28] = acc_fma(Jx[3], Jx[4], acc_fma(Jx[0], Jx[1], pa[28]));
+            pa[29] = acc_fma(Jx[3], Jx[5], acc_fma(Jx[0], Jx[2], pa[29]));
+            pa[30] = acc_fma(Jx[4], Jx[4], acc_fma(Jx[1], Jx[1], pa[30]));
+            pa[31] = acc_fma(Jx[4], Jx[5], acc_fma(Jx[1], Jx[2], pa[31]));
+            pa[32] = acc_fma(Jx[5], Jx[5], acc_fma(Jx[2], Jx[2], pa[32]));
+            pa[33] = acc_fma(Jx[3], r[1], acc_fma(Jx[0], r[0], pa[33]));
+            pa[34] = acc_fma(Jx[4], r[1], acc_fma(Jx[1], r[0], pa[34]));
+            pa[35] = acc_fma(Jx[5], r[1], acc_fma(Jx[2], r[0], pa[35]));
         }
         K2_STAMP(1);
         // ---- Gram of the staged rows on the matrix cores ----
@@ -527,7 +538,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
                 for (int b = 0; b < 3; ++b) {
                     double w[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) w[k] = fma(Jp[6 + k], Jx[3 + b], Jp[k] * Jx[b]);
+                    for (int k = 0; k < 6; ++k) w[k] = acc_fma(Jp[6 + k], Jx[3 + b], Jp[k] * Jx[b]);
                     chol6_forward(A, w);
 #pragma unroll
                     for (int i = 0; i < 6; ++i) Zv[(size_t)i * a.ZC + b * a.P + pid] = w[i];

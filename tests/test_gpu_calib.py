@@ -7,7 +7,7 @@ import pytest
 import cvx_amd
 from cvx_amd import capi
 from conftest import load_golden
-from test_helpers import calib_from_fixture, rel_err
+from test_helpers import assert_params_close, calib_from_fixture, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -176,7 +176,10 @@ def test_full_solve_follows_oracle(orc, case, kind):
         N = d["N"]
         rg = capi.lib().cvx_calib_refine_return(s.final_cost, N)
         assert abs(rg - orc.lib().orc_calib_refine_return(so.final_cost, N)) <= 1e-12 * rg   # RMS, 1e-9 asked
-        assert rel_err(ig, io) < 1e-9 and rel_err(pg, po) < 1e-9 and rel_err(xg, xo) < 1e-9
+        # final parameters BLOCK BY BLOCK (a whole-array norm would measure p1 ~ 1e-3 against fx ~ 1e3): north_star's
+        # 1e-9 on the blocks the gauge freedom moves (rotations, points: measured <= 5.6e-10 / 1.2e-10, config 1), and
+        # ten times the largest measured value (scripts/parity_blocks.py) on the others
+        assert_params_close((ig, pg, xg), (io, po, xo), {"focal_pp": 2e-13, "distortion": 2e-12, "translation": 6e-11}, case)
     else:
         # levmar's machine-epsilon tolerances let the two runs stop a few (flat) iterations apart
         assert s.termination == so.termination

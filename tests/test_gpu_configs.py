@@ -11,7 +11,7 @@ import pytest
 import cvx_amd
 from cvx_amd import capi, formats
 from conftest import GOLDEN, load_golden
-from test_helpers import rel_err
+from test_helpers import assert_params_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,10 @@ def test_config3_stereo_rig_full_solve_follows_oracle(orc):
     assert abs(s.final_cost - so.final_cost) <= 1e-12 * so.final_cost
     rg = capi.lib().cvx_calib_refine_return(s.final_cost, d["N"])
     assert abs(rg - orc.lib().orc_calib_refine_return(so.final_cost, d["N"])) <= 1e-12 * rg
-    assert rel_err(ig, io) < 1e-9 and rel_err(pg, po) < 1e-9 and rel_err(xg, xo) < 1e-9     # 1e-9 asked
+    # block by block; 1e-9 asked, ten times the measured values held (scripts/parity_blocks.py: focal lengths 4.6e-15,
+    # distortion 5.9e-15, rotations 7.9e-13, translations 2.3e-13, points 6.6e-13)
+    assert_params_close((ig, pg, xg), (io, po, xo), {"focal_pp": 5e-14, "distortion": 6e-14, "rotation": 8e-12,
+                                                     "translation": 3e-12, "points": 7e-12}, "config 3")
     # and the answer is the rig that made the data
     assert np.allclose(ig[:, :4], d["intr_gt"][:, :4], rtol=3e-3)
     assert abs(rg - 0.5 * np.sqrt(2) * 0.1) < 0.03 * 0.0707
@@ -118,39 +121,54 @@ def test_config5_full_size_properties(orc):
     g.close()
 
 
-def test_golden_levmar_trace_with_the_gauge_fixed():
+def test_golden_levmar_trace_with_the_gauge_fixed(orc):
     """tests/golden/levmar_calib_fixed_points_trace.json is a run of the REFERENCE's levmar (dense J^T J, LU) on
     BASELINE config 1 with the board points held fixed.  Without the gauge freedom the minimiser is unique and the
-    HIP path (Schur complement + Cholesky, Nielsen damping) must follow that run: every candidate cost of the first
-    iterations to 1e-10, and the final parameters to 1e-9 -- the GPU-vs-reference-output pin of the functor."""
+    HIP path (Schur complement + Cholesky, Nielsen damping) must follow that run: every candidate cost while the run
+    still moves to 1e-10, and the end point block by block.
+
+    Where a levmar run with machine-epsilon tolerances ends is decided by rounding noise: the last twelve candidate
+    costs of the reference run itself wander in the 14th digit (9e-13 of 19.655...), dF > 0 is a coin toss there, and
+    the run stops when enough rejections in a row have shrunk the step.  A cost difference dc cannot tell two points
+    apart that are closer than sqrt(2 dc (S^-1)_ii) in parameter i (S: the reduced normal matrix at the end point) --
+    2.7e-5 px in fx, 1.2e-7 in k2, 1.9e-9 in p2.  Measured on the box (scripts/parity_blocks.py):
+    the HIP run ends 1e-3 .. 3e-3 of that radius away from the reference's end point in EVERY intrinsic (the
+    same fraction for all eight: a displacement along the flat direction, not an error in one block), which is
+    2.5e-11 (focal lengths, principal point), 2.6e-9 (distortion block; 3e-10 absolute in k2), 6.7e-11 (rotations),
+    3.1e-11 (translations) block-relative.  Held at ten times the measured values."""
     gold = load_golden("levmar_calib_fixed_points_trace.json")
     d = cvx_amd.synth_calib(**gold["spec"])
-    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"], fix_points=True)
+    args = (d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    g = cvx_amd.Calib(*args, fix_points=True)
     g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
     s = g.solve(capi.options("levmar"))
     ref = 0.5 * np.array(gold["evals"])
     assert abs(s.initial_cost - ref[0]) <= 1e-13 * ref[0]
     tr = s.trace()["cost"]
-    # candidate costs, one per linear solve, for as long as the run still moves (afterwards dF > 0 is decided by the
-    # last bits and the two runs may part ways by an iteration)
+    # candidate costs, one per linear solve, for as long as the run still moves
     live = np.nonzero(np.abs(ref[1:] - 0.5 * gold["info"][1]) > 1e-7 * 0.5 * gold["info"][1])[0]
     m = min(int(live[-1]) + 1 if len(live) else 0, len(tr))
     assert m >= 8
     assert np.all(np.abs(tr[:m] - ref[1:m + 1]) <= 1e-10 * ref[1:m + 1])
     assert s.termination == int(gold["info"][6])
     assert abs(s.final_cost - 0.5 * gold["info"][1]) <= 1e-12 * s.final_cost
-    intr, poses, _ = g.get_params()
-    exp = np.array(gold["p"])
-    # 1e-9 relative, block by block (the scale of a block is its largest entry: a rotation component that happens to be
-    # 1e-3 rad is not known to 1e-12 rad): focal lengths + principal point, rotations (rad), translations (board units)
-    pe = exp[8:].reshape(-1, 6)
-    assert rel_err(intr[0, :4], exp[:4]) <= 1e-9
-    assert rel_err(poses[:, :3], pe[:, :3]) <= 1e-9 and rel_err(poses[:, 3:], pe[:, 3:]) <= 1e-9
-    # k1 k2 p1 p2 are numbers of size 1e-3 .. 1e-1 that the data determine to an ABSOLUTE accuracy: the run ends when
-    # the step falls below machine epsilon times |p|, where a change of 1e-8 in k2 moves no corner by more than
-    # 1e-7 px.  Held to 1e-8 absolute (measured 3e-10), which is 1e-9 of the block's effect on the image.
-    assert np.max(np.abs(intr[0, [4, 5, 7, 8]] - exp[4:8])) <= 1e-8
+    intr, poses, pts = g.get_params()
     g.close()
+    exp = np.array(gold["p"])
+    ie = d["intr_init"].copy()
+    ie[0, [0, 1, 2, 3, 4, 5, 7, 8]] = exp[:8]
+    pe = exp[8:].reshape(-1, 6)
+    assert_params_close((intr, poses, pts), (ie, pe, d["points_init"]),
+                        {"focal_pp": 3e-10, "distortion": 3e-8, "rotation": 7e-10, "translation": 4e-10, "points": 0.0},
+                        "reference levmar, gauge fixed")
+    # the distance to the reference's end point in units of what the cost can resolve there
+    o = orc.Calib(*args, fix_points=True)
+    S, _, _ = o.reduced_system(ie, pe, d["points_init"], np.zeros(6 * d["V"]), np.zeros(o.ns))
+    tail = np.array(gold["evals"][-12:])
+    dc = 0.5 * (tail.max() - tail.min())
+    radius = np.sqrt(2.0 * dc * np.diag(np.linalg.inv(S)))
+    frac = np.abs(intr[0, [0, 1, 2, 3, 4, 5, 7, 8]] - exp[:8]) / radius
+    assert np.all(frac <= 0.03), frac                     # measured: 1e-3 .. 3e-3
 
 
 def test_files_to_gpu_to_files(orc, tmp_path):
@@ -186,7 +204,8 @@ def test_files_to_gpu_to_files(orc, tmp_path):
     ig, pg, xg = g.get_params()
     g.close()
     assert (s.iterations, s.termination) == (so.iterations, so.termination)
-    assert abs(s.final_cost - so.final_cost) <= 1e-12 * so.final_cost and rel_err(ig, io) < 1e-9
+    assert abs(s.final_cost - so.final_cost) <= 1e-12 * so.final_cost
+    assert_params_close((ig, pg, xg), (io, po, xo), {"focal_pp": 2e-13, "distortion": 2e-12, "translation": 6e-11}, "calib.data")
     K = ig[0, :4]
     dist = ig[0, [4, 5, 7, 8, 6]]                                    # a1 order -> OpenCV's k1 k2 p1 p2 k3 (calibration.cpp:452-456)
     ypath = str(tmp_path / "camera.yaml")

@@ -24,6 +24,45 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300)) if a.size else 0.0
 
 
+def param_block_errs(got, exp):
+    """Per-block relative error of a calibration's parameters, got / exp = (intr[C, 9], poses[V, 6], points[P, 3]):
+    max |a - b| over the block / max |b| over the block, for the blocks whose entries share a unit and a scale --
+    focal lengths + principal point (pixels), distortion coefficients (calibration.cpp:219-229 order: k1 k2 k3 p1 p2),
+    rotations (rad), translations (board units), board points.  A whole-array norm would measure p1 ~ 1e-3 against
+    fx ~ 1e3 and the rotations against the translations.  'dist_cols' holds the distortion block column by column
+    (each coefficient over all cameras against its own largest value)."""
+    (ia, pa, xa), (ib, pb, xb) = [tuple(np.asarray(t, dtype=np.float64) for t in x) for x in (got, exp)]
+    ia, ib = ia.reshape(-1, 9), ib.reshape(-1, 9)
+    pa, pb = pa.reshape(-1, 6), pb.reshape(-1, 6)
+    e = {"focal_pp": rel_err(ia[:, :4], ib[:, :4]), "distortion": rel_err(ia[:, 4:], ib[:, 4:]),
+         "rotation": rel_err(pa[:, :3], pb[:, :3]), "translation": rel_err(pa[:, 3:], pb[:, 3:]),
+         "points": rel_err(xa, xb)}
+    e["dist_cols"] = {n: rel_err(ia[:, 4 + k], ib[:, 4 + k]) for k, n in enumerate(("k1", "k2", "k3", "p1", "p2"))
+                      if np.any(ib[:, 4 + k] != 0.0)}
+    return e
+
+
+# north_star's bar for the final intrinsics / extrinsics
+PARAM_TOL_NORTH_STAR = {"focal_pp": 1e-9, "distortion": 1e-9, "rotation": 1e-9, "translation": 1e-9, "points": 1e-9}
+
+
+def assert_params_close(got, exp, tol=None, what=""):
+    """Every block of param_block_errs within its tolerance: tol maps block name -> bound (missing names: 1e-9,
+    north_star's figure for intrinsics / extrinsics); a key of dist_cols (k1 .. p2) bounds that column on its own."""
+    t = dict(PARAM_TOL_NORTH_STAR)
+    t.update(tol or {})
+    e = param_block_errs(got, exp)
+    for k, bound in t.items():
+        if k in e:
+            v = e[k]
+        elif k in e["dist_cols"]:
+            v = e["dist_cols"][k]
+        else:
+            continue                    # a column that is zero everywhere (k3 fixed at 0)
+        assert v <= bound, "%s block %s: %.3g > %.3g (%s)" % (what, k, v, bound, e)
+    return e
+
+
 def calib_from_fixture(g):
     """functor_mp.json 'calib' block -> arrays of a calibration problem (8 views x 4 points, 2 cameras)."""
     V, P = len(g["poses"]), len(g["points"])
