@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/cvx_amd.h"
 
@@ -28,5 +29,10 @@ inline int hip_fail(hipError_t e, const char *what, const char *file, int line) 
 // blocked Cholesky solve of an SPD system on the host: A (n x n row-major, lower triangle
 // read, destroyed), b in/out.  Returns false when A is not numerically positive definite.
 bool host_cholesky_solve(int n, double *A, double *b);
+
+// One-sided (Hestenes) Jacobi SVD of an m x k matrix (row-major, k <= 8), handeye_init.cpp: on return the columns of
+// W = A V are mutually orthogonal; sv[j] = |W_j| descending, V (k x k, row-major) holds the right singular vectors
+// as columns.
+void jacobi_svd(std::vector<double> &W, int m, int k, double *V, double *sv);
 
 }  // namespace cvx

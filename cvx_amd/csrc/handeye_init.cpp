@@ -13,11 +13,9 @@
 
 #include "common.h"
 
-namespace {
-
 // One-sided Jacobi SVD of an m x k matrix (row-major, k <= 8): on return the columns of W = A V are mutually
 // orthogonal; sv[j] = |W_j| descending, V (k x k, row-major) holds the right singular vectors as columns.
-void jacobi_svd(std::vector<double> &W, int m, int k, double *V, double *sv) {
+void cvx::jacobi_svd(std::vector<double> &W, int m, int k, double *V, double *sv) {
     for (int i = 0; i < k; ++i)
         for (int j = 0; j < k; ++j) V[i * k + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -68,6 +66,9 @@ void jacobi_svd(std::vector<double> &W, int m, int k, double *V, double *sv) {
     std::memcpy(V, Vs, sizeof(double) * k * k);
     W.swap(Ws);
 }
+
+namespace {
+using cvx::jacobi_svd;
 
 // JacobiSVD(A, ComputeThinU | ComputeThinV).solve(b): x = V S^-1 U^T b (singular values below
 // eps * max(m, k) * s_max are dropped, Eigen's default threshold)
@@ -186,20 +187,22 @@ int linear_dual_quaternion(const std::vector<Motion> &A, const std::vector<Motio
     }
     double V[64], sv[8];
     jacobi_svd(T, 6 * n, 8, V, sv);
-    double v7[8], v8[8];
-    for (int r = 0; r < 8; ++r) { v7[r] = V[r * 8 + 6]; v8[r] = V[r * 8 + 7]; }
-    auto dot4 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; };
-    const double *u1 = v7, *v1 = v7 + 4, *u2 = v8, *v2 = v8 + 4;
-    const double a = dot4(u1, v1), b = dot4(u1, v2) + dot4(u2, v1), c = dot4(u2, v2);
-    const double det = std::sqrt(b * b - 4 * a * c);
-    const double s1 = (-b + det) / 2 / a, s2 = (-b - det) / 2 / a;
-    const double a_ = dot4(u1, u1), b_ = dot4(u1, u2), c_ = dot4(u2, u2);
-    const double val1 = s1 * s1 * a_ + 2 * s1 * b_ + c_, val2 = s2 * s2 * a_ + 2 * s2 * b_ + c_;
-    double s, val;
-    if (val1 > val2) { s = s1; val = val1; } else { s = s2; val = val2; }
-    const double lambda2 = std::sqrt(1 / val), lambda1 = s * lambda2;
+    // the two right singular vectors of the smallest singular values span the solutions (q, q'); the unit-norm and
+    // orthogonality conditions q.q = 1, q.q' = 0 pick the combination mu (ns_a + ratio ns_b): a quadratic in ratio
+    double ns_a[8], ns_b[8];
+    for (int r = 0; r < 8; ++r) { ns_a[r] = V[r * 8 + 6]; ns_b[r] = V[r * 8 + 7]; }
+    auto dot4 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3]; };
+    const double *real_a = ns_a, *dual_a = ns_a + 4, *real_b = ns_b, *dual_b = ns_b + 4;
+    const double qa2 = dot4(real_a, dual_a), qa1 = dot4(real_a, dual_b) + dot4(real_b, dual_a), qa0 = dot4(real_b, dual_b);
+    const double disc = std::sqrt(qa1 * qa1 - 4 * qa2 * qa0);
+    const double root[2] = {(-qa1 + disc) / 2 / qa2, (-qa1 - disc) / 2 / qa2};
+    // |real part|^2 of (root ns_a + ns_b): the root with the larger value is the better conditioned one (handeye.cpp:441-452)
+    const double naa = dot4(real_a, real_a), nab = dot4(real_a, real_b), nbb = dot4(real_b, real_b);
+    const double norm2[2] = {root[0] * root[0] * naa + 2 * root[0] * nab + nbb, root[1] * root[1] * naa + 2 * root[1] * nab + nbb};
+    const int pick = norm2[0] > norm2[1] ? 0 : 1;
+    const double w_b = std::sqrt(1 / norm2[pick]), w_a = root[pick] * w_b;
     double sol[8];
-    for (int r = 0; r < 8; ++r) sol[r] = lambda1 * v7[r] + lambda2 * v8[r];
+    for (int r = 0; r < 8; ++r) sol[r] = w_a * ns_a[r] + w_b * ns_b[r];
     if (!std::isfinite(sol[0])) return CVX_ERR_NUMERIC;
     const double *q = sol, *qp = sol + 4;
     double R[9];

@@ -174,12 +174,58 @@ extern "C" void cvx_angle_axis_to_rotation(const double w[3], double R[9]) {
 }
 #undef RR
 
-extern "C" void cvx_affine_to_quat_trans(const double T[16], double q[4], double t[3]) {
-    // Quaterniond(A.rotation()), A.translation()  (handeye.cpp:287-290); the linear part is
-    // taken as the rotation (Affine3d::rotation() returns it for a rigid transform)
-    double R[9];
+// Eigen's Transform<double,3,Affine>::rotation() (what handeye.cpp:287-290 converts to a quaternion): the orthogonal
+// factor of the polar decomposition of the linear part L = U S V^T, rotation = U diag(1/x, 1, 1) V^T with
+// x = det(U V^T) = +-1 dividing U's FIRST column (Transform::computeRotationScaling of Eigen 3.2 / 3.3, the
+// versions the reference's Ceres <= 2.1 API dates it to; Eigen 3.4 flips the last column instead -- the two agree
+// whenever det L > 0, which every rigid or noisy-rigid pose has).  [external: Eigen is not in /root/reference]
+// R, out: column-major 3x3.  A linear part that is orthonormal to rounding (|L^T L - I| <= 64 eps) is its own polar
+// factor to rounding and is returned as it is, bit for bit; Eigen's SVD would return it perturbed in the last
+// bits, by its own rounding, which no restatement reproduces.
+static void polar_rotation(const double L[9], double out[9]) {
+    double dev = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += L[i * 3 + k] * L[j * 3 + k];       // columns i and j
+            dev = std::max(dev, std::fabs(s - (i == j ? 1.0 : 0.0)));
+        }
+    if (!(dev > 64 * 2.220446049250313e-16)) {
+        std::memcpy(out, L, 9 * sizeof(double));
+        return;
+    }
+    std::vector<double> W(9);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W[i * 3 + j] = L[j * 3 + i];                // row-major copy
+    double V[9], sv[3];
+    cvx::jacobi_svd(W, 3, 3, V, sv);                                            // W = U S (columns), sv descending
+    double U[9];
     for (int j = 0; j < 3; ++j)
-        for (int i = 0; i < 3; ++i) R[j * 3 + i] = T[j * 4 + i];
+        for (int i = 0; i < 3; ++i) U[i * 3 + j] = sv[j] > 0.0 ? W[i * 3 + j] / sv[j] : 0.0;
+    if (!(sv[2] > 1e-300 * sv[0])) {
+        // rank-deficient linear part: complete U to an orthonormal basis (Eigen's full U is one too)
+        if (!(sv[1] > 1e-300 * sv[0])) { std::memcpy(out, L, 9 * sizeof(double)); return; }
+        U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+        U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+        U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+    }
+    double Q[9];                                                                // U V^T, row-major
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Q[i * 3 + j] = U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1] + U[i * 3 + 2] * V[j * 3 + 2];
+    const double x = Q[0] * (Q[4] * Q[8] - Q[5] * Q[7]) - Q[1] * (Q[3] * Q[8] - Q[5] * Q[6]) + Q[2] * (Q[3] * Q[7] - Q[4] * Q[6]);
+    if (x < 0.0)                                                                // m.col(0) /= x
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Q[i * 3 + j] -= 2.0 * U[i * 3] * V[j * 3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[j * 3 + i] = Q[i * 3 + j];
+}
+
+extern "C" void cvx_affine_to_quat_trans(const double T[16], double q[4], double t[3]) {
+    // Quaterniond(A.rotation()), A.translation()  (handeye.cpp:287-290)
+    double L[9], R[9];
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) L[j * 3 + i] = T[j * 4 + i];
+    polar_rotation(L, R);
     cvx_rotation_to_quaternion(R, q);
     t[0] = T[12]; t[1] = T[13]; t[2] = T[14];
 }

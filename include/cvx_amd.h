@@ -269,7 +269,9 @@ void cvx_rotation_to_angle_axis(const double R_colmajor[9], double w[3]);
 void cvx_angle_axis_to_rotation(const double w[3], double R_colmajor[9]);
 /* Eigen::Quaterniond(R) on a column-major 3x3; q = (w,x,y,z) */
 void cvx_rotation_to_quaternion(const double R_colmajor[9], double q[4]);
-/* 4x4 column-major rigid transforms -> (q, t) of handeye.cpp:286-291 */
+/* 4x4 column-major transforms -> (q, t) of handeye.cpp:286-291: q = Quaterniond(A.rotation()), where rotation() is the
+ * orthogonal polar factor of the linear part (Eigen 3.3's computeRotationScaling); a linear part that is orthonormal
+ * to rounding is converted as it is */
 void cvx_affine_to_quat_trans(const double T_colmajor[16], double q[4], double t[3]);
 /* X = Translation(t) * q.toRotationMatrix(), handeye.cpp:326-330 */
 void cvx_quat_trans_to_affine(const double p[7], double T_colmajor[16]);

@@ -100,6 +100,63 @@ def test_rotation_conversions_round_trip_and_match_oracle(orc):
         assert np.allclose(T.reshape(4, 4).T[:3, 3], [1, 2, 3])
 
 
+def test_affine_rotation_is_the_polar_factor():
+    """cvx_affine_to_quat_trans restates Quaterniond(Affine3d::rotation()) (handeye.cpp:287-290): rotation() is the
+    orthogonal polar factor of the linear part (Eigen's computeRotationScaling: U diag(1/x, 1, 1) V^T, x = det(U V^T)).
+    Rigid inputs -- exact rotations and products of them, as the motion pairs are -- keep the bits of the plain
+    conversion; a noisy 4x4 (a pose_N.txt written with six digits) gives the quaternion of its nearest rotation."""
+    from cvx_amd.capi import lib, pd
+    L = lib()
+    rng = np.random.default_rng(3)
+
+    def rot(w):
+        R = np.zeros(9)
+        L.cvx_angle_axis_to_rotation(pd(np.asarray(w, float)), pd(R))
+        return R.reshape(3, 3).T                               # column-major -> numpy
+
+    def quat_of_affine(M):
+        T = np.ascontiguousarray(M.T).reshape(-1)              # column-major
+        q, t = np.zeros(4), np.zeros(3)
+        L.cvx_affine_to_quat_trans(pd(T), pd(q), pd(t))
+        return q, t
+
+    def quat_of_rotation(R):
+        q = np.zeros(4)
+        L.cvx_rotation_to_quaternion(pd(np.ascontiguousarray(R.T).reshape(-1)), pd(q))
+        return q
+
+    def eigen_rotation(A):                                     # Transform::computeRotationScaling, Eigen 3.3
+        U, s, Vt = np.linalg.svd(A)
+        x = np.linalg.det(U @ Vt)
+        U = U.copy(); U[:, 0] /= x
+        return U @ Vt
+
+    for k in range(50):
+        Ra, Rb = rot(rng.normal(size=3)), rot(rng.normal(size=3) * 2.0)
+        for R in (Ra, Ra @ Rb.T, Ra @ Rb @ Ra):                # exact, and products as A = G_j G_i^-1 are
+            M = np.eye(4); M[:3, :3] = R; M[:3, 3] = rng.normal(size=3)
+            q, t = quat_of_affine(M)
+            assert np.array_equal(q, quat_of_rotation(R)) and np.array_equal(t, M[:3, 3])
+        # noisy linear part: rounded to six digits, and a grossly non-rigid one (scale + shear)
+        for A in (np.round(Ra, 6), Ra @ (np.eye(3) + 0.05 * rng.normal(size=(3, 3))), 1.7 * Rb):
+            M = np.eye(4); M[:3, :3] = A; M[:3, 3] = rng.normal(size=3)
+            q, t = quat_of_affine(M)
+            assert abs(np.linalg.norm(q) - 1.0) < 1e-14        # an orthonormal R gives a unit quaternion
+            Rq = np.zeros(16)
+            L.cvx_quat_trans_to_affine(pd(np.concatenate([q, t])), pd(Rq))
+            Rq = Rq.reshape(4, 4).T[:3, :3]
+            assert np.max(np.abs(Rq.T @ Rq - np.eye(3))) < 1e-14 and np.linalg.det(Rq) > 0
+            assert np.max(np.abs(Rq - eigen_rotation(A))) < 1e-13
+            assert np.max(np.abs(quat_of_rotation(A) - q)) > 1e-9       # the plain conversion would differ
+    # a reflection: Eigen 3.3 flips U's first column
+    A = rot([0.3, -0.2, 0.5]) @ np.diag([1.0, 1.0, -1.0]) @ (np.eye(3) + 0.01 * rng.normal(size=(3, 3)))
+    M = np.eye(4); M[:3, :3] = A
+    q, _ = quat_of_affine(M)
+    Rq = np.zeros(16)
+    L.cvx_quat_trans_to_affine(pd(np.concatenate([q, np.zeros(3)])), pd(Rq))
+    assert np.max(np.abs(Rq.reshape(4, 4).T[:3, :3] - eigen_rotation(A))) < 1e-13
+
+
 def test_synthetic_calibration_workload_is_deterministic_and_float32_representable():
     a = cvx_amd.synth_calib(2, 5, 12, 9, 20260003)
     b = cvx_amd.synth_calib(2, 5, 12, 9, 20260003)
