@@ -491,7 +491,11 @@ int ensure_inner(cvx_calib *h) {
 // View-sharded runs: pose blocks are a rank's own; a camera's or a point's observations are spread over the ranks,
 // so in a set that holds such blocks every round all-reduces their sums (H | g | cost rows, then the candidates'
 // costs) and the count of blocks that go on -- the ranks then take the same decisions and leave the set together.
-int inner_pass(cvx_calib *h, int which) {
+// A set of pose blocks only runs a rank-local number of rounds, so its round limit can strike on one rank alone: on a
+// sharded handle that failure is handed back in *rank_local_status and the pass goes on through the remaining sets'
+// collectives; the caller agrees on it with the other ranks (agree_on_status) so that all return the error together.
+int inner_pass(cvx_calib *h, int which, int *rank_local_status) {
+    *rank_local_status = CVX_OK;
     int st = ensure_inner(h);
     if (st) return st;
     const int NB = h->C + h->P + h->V, nsh = h->C + h->P;
@@ -518,7 +522,11 @@ int inner_pass(cvx_calib *h, int which) {
         a.cur = set;
         hipLaunchKernelGGL(cvxi::k_inner_reset, per_block, t64, 0, h->stream, a);
         for (int round = 0;; ++round) {
-            if (round > 60) { cvx::set_last_error("inner iterations: a block did not terminate"); return CVX_ERR_NUMERIC; }
+            if (round > 60) {
+                cvx::set_last_error("inner iterations: a block did not terminate");
+                if (sharded && !shared) { *rank_local_status = CVX_ERR_NUMERIC; break; }
+                return CVX_ERR_NUMERIC;     // a shared set's round count is the same on every rank
+            }
             // blocks of the shared kinds: partial sums, then one fixed-order sum per block (ids 0 .. C + P - 1)
             const dim3 pt_grid(h->P, h->pt_slices), shared_grid(nsh);
             if (poses) hipLaunchKernelGGL(cvxi::k_inner_pose<0>, dim3((h->V + 3) / 4), dim3(256), 0, h->stream, a);
@@ -560,6 +568,10 @@ int inner_pass(cvx_calib *h, int which) {
     }
     return CVX_OK;
 }
+
+// max over the ranks of a status that may differ between them, riding as one more entry of an exchange the caller makes
+// anyway (statuses are small non-negative integers; a sum over the ranks is non-zero iff any is)
+int agreed_status(double summed) { return summed != 0.0 ? CVX_ERR_NUMERIC : CVX_OK; }
 
 class CalibEvaluator : public cvx::Evaluator {
 public:
@@ -647,7 +659,8 @@ public:
     // the candidate of the last try_step goes through one inner-iteration pass
     int inner_iterations(double *cost, double *step_norm2) override {
         const int nxt = 1 - h->cur;
-        int st = inner_pass(h, nxt);
+        int local = CVX_OK;
+        int st = inner_pass(h, nxt, &local);
         if (st) return st;
         hipLaunchKernelGGL(cvxi::k_inner_step_norm, dim3(1), dim3(1024), 0, h->stream, h->d_intr[h->cur], h->d_intr[nxt],
                            9LL * h->C, h->d_points[h->cur], h->d_points[nxt], 3LL * h->P, h->d_poses[h->cur], h->d_poses[nxt],
@@ -657,10 +670,16 @@ public:
         st = cost_of(h, nxt, cost);         // synchronises the stream
         if (st) return st;
         if (h->nranks > 1 && h->xfn) {      // the cost and the poses' part of the norm are this rank's share
-            std::vector<double> v = {*cost, h->h_ib_active[2]};
+            std::vector<double> v = {*cost, h->h_ib_active[2], local ? 1.0 : 0.0};
             st = exchange_sum_host(h, v);
             if (st) return st;
             *cost = v[0]; h->h_ib_active[2] = v[1];
+            if (agreed_status(v[2])) {
+                if (!local) cvx::set_last_error("inner iterations: a block did not terminate on another rank");
+                return CVX_ERR_NUMERIC;
+            }
+        } else if (local) {
+            return local;
         }
         *step_norm2 = h->h_ib_active[1] + h->h_ib_active[2];
         return CVX_OK;
@@ -1062,8 +1081,17 @@ extern "C" int cvx_calib_cost(cvx_calib *h, double *cost) {
 extern "C" int cvx_calib_inner_pass(cvx_calib *h, double *cost) {
     if (!h) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
-    int st = inner_pass(h, h->cur);
+    int local = CVX_OK;
+    int st = inner_pass(h, h->cur, &local);
     if (st) return st;
+    if (h->nranks > 1 && h->xfn) {          // all ranks leave with the same status
+        std::vector<double> v = {local ? 1.0 : 0.0};
+        st = exchange_sum_host(h, v);
+        if (st) return st;
+        if (agreed_status(v[0])) return CVX_ERR_NUMERIC;
+    } else if (local) {
+        return local;
+    }
     double c = 0;
     st = cost_of(h, h->cur, &c);
     if (cost) *cost = c;

@@ -2,6 +2,7 @@
 // Replaces the body of HandEyeCalibration::solveNonLinear between "p[7] packed" and
 // "X rebuilt" (/root/reference/modules/calib/src/handeye.cpp:282-324).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -289,7 +290,7 @@ namespace {
 constexpr int HE_STATIC_BLOCKS = CVX_HANDEYE_STATIC_MAX_PAIRS / 256;
 constexpr int HE_STATIC_MAX_DEVICES = 64;
 static __device__ __align__(256) double scratch[(size_t)HE_STATIC_BLOCKS * HE_ACC];
-double *g_scratch_ptr[HE_STATIC_MAX_DEVICES];
+std::atomic<double *> g_scratch_ptr[HE_STATIC_MAX_DEVICES];
 std::mutex g_scratch_mutex;
 }  // namespace
 
@@ -302,25 +303,39 @@ extern "C" int cvx_handeye_normal_eq_static(int n_pairs, const double *d_qa, con
                             std::to_string(CVX_HANDEYE_STATIC_MAX_PAIRS) + "), the size its fixed scratch array holds");
         return CVX_ERR_UNSUPPORTED;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        cvx::set_last_error("no HIP device visible");
-        return CVX_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= ndev) return CVX_ERR_NO_DEVICE;
+    if (device < 0) return CVX_ERR_NO_DEVICE;
     if (device >= HE_STATIC_MAX_DEVICES) return CVX_ERR_UNSUPPORTED;
-    CVX_HIP(hipSetDevice(device));
-    double *partial = nullptr;
-    {
+    // The calling thread's current device is left as it was found.  After the first call on a device the call takes
+    // no lock and asks the runtime nothing but the current device.
+    int prev = -1;
+    CVX_HIP(hipGetDevice(&prev));
+    double *partial = g_scratch_ptr[device].load(std::memory_order_acquire);
+    if (prev != device || !partial) {
+        if (!partial) {
+            int ndev = 0;
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+                cvx::set_last_error("no HIP device visible");
+                return CVX_ERR_NO_DEVICE;
+            }
+            if (device >= ndev) return CVX_ERR_NO_DEVICE;
+        }
+        CVX_HIP(hipSetDevice(device));
+    }
+    struct RestoreDevice {
+        int prev, now;
+        ~RestoreDevice() { if (prev != now && prev >= 0) (void)hipSetDevice(prev); }
+    } restore{prev, device};
+    if (!partial) {
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
-        if (!g_scratch_ptr[device]) {
+        partial = g_scratch_ptr[device].load(std::memory_order_relaxed);
+        if (!partial) {
             // first call on this device (make it outside any stream capture): this GPU's copy of the array
             double *ptr = nullptr;
             CVX_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
             if (!ptr) { cvx::set_last_error("hipGetSymbolAddress returned a null address"); return CVX_ERR_HIP; }
-            g_scratch_ptr[device] = ptr;
+            g_scratch_ptr[device].store(ptr, std::memory_order_release);
+            partial = ptr;
         }
-        partial = g_scratch_ptr[device];
     }
     // same grid as the handle's launch, so the sums (and their order) are the same
     const long long n = n_pairs;
@@ -344,6 +359,11 @@ extern "C" int cvx_handeye_set_exchange(cvx_handeye *h, cvx_allreduce_fn fn, voi
 
 extern "C" int cvx_handeye_solve(cvx_handeye *h, double p[7], const cvx_lm_options *opt, cvx_lm_summary *summary) {
     if (!h || !p || !opt || !summary) return CVX_ERR_INVALID_ARG;
+    if (opt->strategy == 0 && opt->inner_iterations) {
+        // one parameter block pair (q, t) with every residual on both: no independent sets to descend over
+        cvx::set_last_error("hand-eye has one parameter block: inner iterations unsupported");
+        return CVX_ERR_UNSUPPORTED;
+    }
     CVX_HIP(hipSetDevice(h->device));
     HandEyeEvaluator ev(h, p);
     int st = cvx::lm_minimize(ev, *opt, *summary);

@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(64) k_inner_decide(InnerArgs a) {
         double f = 1.0 - t * t * t;
         if (f < 1.0 / 3.0) f = 1.0 / 3.0;
         double radius = st[ST_RADIUS] / f;
-        if (radius > 1e16) radius = 1e16;
+        if (radius > 1e32) radius = 1e32;       // TrustRegionStrategy::Options::max_radius (not Solver::Options' 1e16)
         st[ST_RADIUS] = radius; st[ST_DECREASE] = 2.0;
         fl[FL_PHASE] = PH_LIN;
     } else {

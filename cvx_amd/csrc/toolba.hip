@@ -201,7 +201,7 @@ struct BlockLM3 {
         const double rho = (cost - cand) / model;
         if (rho > 1e-3) {
             const double t = 2.0 * rho - 1.0;
-            radius = std::min(radius / std::max(1.0 / 3.0, 1.0 - t * t * t), 1e16);
+            radius = std::min(radius / std::max(1.0 / 3.0, 1.0 - t * t * t), 1e32);    // TrustRegionStrategy::Options::max_radius
             decrease = 2.0;
             needs_lin = true;
             return true;

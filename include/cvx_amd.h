@@ -251,7 +251,9 @@ int cvx_handeye_evaluate(cvx_handeye *h, const double p[7], double *r, double *J
  * library's device image (229 376 bytes on every GPU the library runs on, held until the process ends), hence the
  * limit: n_pairs > CVX_HANDEYE_STATIC_MAX_PAIRS returns CVX_ERR_UNSUPPORTED.  All calls on one GPU share that
  * array: calls that overlap on one GPU (two streams, two threads) race; calls ordered on one stream do not.
- * The first call on a device looks up the array's address there: make it outside any stream capture.
+ * The first call on a device looks up the array's address there: make it outside any stream capture.  `device` is
+ * made current for the launches and the calling thread's current device is restored before the call returns;
+ * `stream` must belong to `device` (not checked).
  * Results are bit-identical to cvx_handeye_normal_eq on the same pairs. */
 #define CVX_HANDEYE_STATIC_MAX_PAIRS 262144
 int cvx_handeye_normal_eq_static(int n_pairs, const double *d_qa, const double *d_ta, const double *d_qb,

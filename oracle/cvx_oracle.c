@@ -1252,6 +1252,7 @@ double orc_calib_inner_pass(const orc_calib_problem *pb, double *intr, double *p
             pt_obs[pt_off[p] + fill[p]++] = o; view_of_obs[o] = v;
         }
     orc_lm_options io; lm_defaults(&io);        /* CoordinateDescentMinimizer::Solve: a default Minimizer::Options */
+    io.max_radius = 1e32;                       /* ... and a default TrustRegionStrategy::Options (max_radius 1e32) */
     orc_lm_summary *isum = malloc(sizeof *isum);
     for (int gi = 0; gi < ng; ++gi)
         for (int b = 0; b < NB; ++b) {
@@ -1797,6 +1798,7 @@ double orc_toolba_inner_pass(const orc_toolba_problem *pb, double p[7], double *
     int n_used = 0;
     for (int o = 0; o < pb->N; ++o) if (!used[pb->point_id[o]]) { used[pb->point_id[o]] = 1; ++n_used; }
     orc_lm_options io; lm_defaults(&io);
+    io.max_radius = 1e32;                       /* default TrustRegionStrategy::Options, as in orc_calib_inner_pass */
     orc_lm_summary *isum = malloc(sizeof *isum);
     /* the order of the sets, as block types: 0 t, 1 q, 2 points */
     int order[3] = { 0, 1, 2 };

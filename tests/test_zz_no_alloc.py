@@ -26,11 +26,23 @@ _HIP = None
 def _hip():
     global _HIP
     if _HIP is None:
-        capi.lib()                                   # the library's own libamdhip64.so.7 is then the one in the process
-        _HIP = C.CDLL("libamdhip64.so.7")
+        capi.lib()
+        # the HIP runtime libcvx_amd.so itself brought into the process (whatever its version), not a soname of ours
+        paths = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64.so" in l}
+        assert len(paths) == 1, paths
+        _HIP = C.CDLL(paths.pop())
         _HIP.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _HIP.hipFree.argtypes = [C.c_void_p]
+        _HIP.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        _HIP.hipStreamDestroy.argtypes = [C.c_void_p]
+        _HIP.hipStreamSynchronize.argtypes = [C.c_void_p]
+        _HIP.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+        _HIP.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        _HIP.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        _HIP.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        _HIP.hipGraphExecDestroy.argtypes = [C.c_void_p]
+        _HIP.hipGraphDestroy.argtypes = [C.c_void_p]
     return _HIP
 
 
@@ -93,3 +105,36 @@ def test_static_entry_point_rejects_sizes_beyond_its_scratch():
     g.close()
     Hs, gs, cs = _static(n, qa, ta, qb, tb, p7)
     assert np.array_equal(Hs, H) and np.array_equal(gs, gr) and cs == c
+
+
+def test_static_entry_point_under_stream_capture():
+    """What the entry point is for: after the first (address look-up) call on the device, a call between
+    hipStreamBeginCapture and hipStreamEndCapture on a non-default stream, in global capture mode -- where hipMalloc,
+    hipFree and every synchronising call fail and invalidate the capture -- succeeds, records its two kernels, and the
+    replayed graph gives the handle path's bits, twice (the graph re-uses the scratch array)."""
+    hip = _hip()
+    p7 = np.array([0.7, -0.2, 0.4, 0.1, 0.3, -0.1, 0.02])
+    n = 5000
+    qa, ta, qb, tb = _pairs(n, 21)
+    g = cvx_amd.HandEye(qa, ta, qb, tb)
+    H, gr, c = g.normal_eq(p7)
+    g.close()
+    _static(64, *_pairs(64, 22), p7)                          # the look-up call, outside any capture
+    bufs = [_Dev(a) for a in (qa, ta, qb, tb, p7)]
+    out = _Dev(np.full(43, np.nan))
+    stream, graph, gexec = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    assert hip.hipStreamBeginCapture(stream, 0) == 0          # hipStreamCaptureModeGlobal
+    st = capi.lib().cvx_handeye_normal_eq_static(n, bufs[0].p, bufs[1].p, bufs[2].p, bufs[3].p, bufs[4].p, out.p, 0, stream)
+    end = hip.hipStreamEndCapture(stream, C.byref(graph))
+    assert st == capi.OK and end == 0 and graph.value        # an allocation inside would have broken the capture
+    assert np.all(np.isnan(out.host()))                      # captured, not run
+    assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
+    for _ in range(2):
+        assert hip.hipGraphLaunch(gexec, stream) == 0 and hip.hipStreamSynchronize(stream) == 0
+        o = out.host()
+        assert np.array_equal(o[:36].reshape(6, 6), H) and np.array_equal(o[36:42], gr) and o[42] == c
+        assert hip.hipMemcpy(out.p, np.full(43, np.nan).ctypes.data_as(C.c_void_p), 8 * 43, 1) == 0
+    hip.hipGraphExecDestroy(gexec); hip.hipGraphDestroy(graph); hip.hipStreamDestroy(stream)
+    for b in bufs + [out]:
+        b.free()
