@@ -232,6 +232,73 @@ def toolba_bench(cvx_amd, torch, device, with_cpu, V=CAMERAS * VIEWS_PER_CAMERA,
     return out
 
 
+def lm_iteration_ms(cvx_amd, capi, torch, spec, device, steps=20, hook=None, rank=0, world=1, fence=None, host_exchange=False):
+    """ms per LM iteration (the same step as the headline: no inner-iteration passes, every iteration asked is run) of the
+    synthetic calibration problem `spec` = (cameras, views per camera, board w, board h, seed); with world > 1 the
+    problem's views are cut over the ranks (strong scaling) and the exchange goes through `hook`."""
+    C_, VP, bw, bh, seed = spec
+    full = cvx_amd.synth_calib(C_, VP, bw, bh, seed)
+    n_total, v_total = full["N"], full["V"]
+    if world > 1:
+        first = cvx_amd.partition_views(full["view_off"], world)
+        d = cvx_amd.shard_calib(full, first, rank)
+    else:
+        d = full
+    intr0, pts0 = full["intr_init"], full["points_init"]       # the generator is deterministic: the same on every rank
+    del full
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], C_, bw * bh,
+                          device=device, stream=stream.cuda_stream)
+        if world > 1:
+            g.set_exchange(hook, rank, world, device_buffers=not host_exchange)
+        o = capi.options("refine")
+        o.inner_iterations = 0
+        o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = -1.0
+        o.max_iterations = ITERS_PER_SOLVE
+
+        def run(n):
+            for _ in range(max(1, n // ITERS_PER_SOLVE)):
+                g.set_params(intr0, d["poses_init"], pts0)
+                s = g.solve(o)
+                if s.iterations != ITERS_PER_SOLVE:
+                    raise RuntimeError("solve stopped after %d iterations (termination %d)" % (s.iterations, s.termination))
+            return s
+        run(ITERS_PER_SOLVE)
+        if fence:
+            fence()
+        else:
+            torch.cuda.synchronize()
+        t = time.perf_counter()
+        s = run(steps)
+        if fence:
+            fence()
+        else:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        ns = g.ns
+        g.close()
+    n_steps = max(1, steps // ITERS_PER_SOLVE) * ITERS_PER_SOLVE
+    return {"observations": n_total, "pose_blocks": v_total, "shared_unknowns": ns, "steps": n_steps,
+            "views_this_rank": d["V"], "seconds": dt, "ms_per_lm_iteration": 1e3 * dt / n_steps,
+            "cost": [s.initial_cost, s.final_cost]}
+
+
+def handeye_cpu_baseline(q, x0, iters):
+    """solveNonLinear (handeye.cpp:272-333) of the oracle on the same motion pairs, one thread"""
+    from oracle import oracle as orc
+    ho = orc.HandEye(*q)
+    op = orc.options("handeye")
+    op.function_tolerance = op.gradient_tolerance = op.parameter_tolerance = -1.0
+    op.max_iterations = iters
+    t = time.perf_counter()
+    p, s = ho.solve(x0, op)
+    dt = time.perf_counter() - t
+    n = max(s.iterations, 1)
+    return {"value": 1e3 * dt / n, "unit": "ms per LM iteration", "cores": 1, "kind": "port",
+            "sample": "the same %d motion pairs, %d LM iterations, %.3f s" % (len(q[0]), n, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -413,6 +480,31 @@ def main():
         eval_ms = e0.elapsed_time(e1) / n_eval
         g.close()
 
+    # ---- the other calibration configurations of BASELINE.json, the same step (ms per LM iteration) ----
+    configs = config5_strong = None
+    if world == 1:
+        configs = {}
+        for name, spec in (("config1", (1, 20, 9, 6, 20260001)), ("config3", (2, 500, 12, 9, 20260003)),
+                           ("config5", (8, 12500, 12, 9, 20260005))):
+            r = lm_iteration_ms(cvx_amd, capi, torch, spec, local_rank, steps=20)
+            r["observation_iterations_per_s"] = r["observations"] * r["steps"] / r["seconds"]
+            configs[name] = r
+    else:
+        # north_star's config 5 ("100k views x 108 corners, 8xMI355X"): ONE 10.8 M-observation problem cut by view over
+        # the ranks -- the configuration where the per-rank kernels dominate the replicated reduced solve
+        trace("config 5, strong")
+        r = lm_iteration_ms(cvx_amd, capi, torch, (8, 12500, 12, 9, 20260005), local_rank, steps=20, hook=hook, rank=rank,
+                            world=world, fence=fence, host_exchange=a.host_exchange)
+        tt = on_wire(torch.tensor([r["seconds"]], dtype=torch.float64))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        r["seconds"] = float(tt.item())
+        r["ms_per_lm_iteration"] = 1e3 * r["seconds"] / r["steps"]
+        r["value"] = r["observations"] * r["steps"] / r["seconds"]
+        r.update(unit="observations/s", n_gpus=world, scaling="strong",
+                 workload="BASELINE config 5: 8 cameras x 12500 views x 12x9 board, ONE problem sharded by view over %d GPUs" % world)
+        config5_strong = r
+        trace("config 5 done")
+
     # ---- BASELINE config 2: hand-eye AX = XB refinement, 200 poses (launch-latency-bound by construction:
     #      SURVEY.md 8d asks for time per LM iteration only) ----
     handeye = None
@@ -421,7 +513,8 @@ def main():
         for name, moving in (("fixed_camera_all_pairs", False), ("moving_camera_consecutive_pairs", True)):
             G, T, xgt, x0 = cvx_amd.synth_handeye(200, 20260002, moving=moving)
             A, B = cvx_amd.handeye_pairs(G, T, moving=moving)
-            he = cvx_amd.HandEye(*cvx_amd.pairs_to_quat_trans(A, B), device=local_rank)
+            q = cvx_amd.pairs_to_quat_trans(A, B)
+            he = cvx_amd.HandEye(*q, device=local_rank)
             ho = capi.options("handeye")
             ho.function_tolerance = ho.gradient_tolerance = ho.parameter_tolerance = -1.0
             ho.max_iterations = 20
@@ -435,6 +528,8 @@ def main():
             handeye[name] = {"pairs": int(len(A)), "ms_per_lm_iteration": 1e3 * (time.perf_counter() - th) / (reps * max(hs.iterations, 1)),
                              "iterations_per_solve": hs.iterations, "final_cost": hs.final_cost}
             he.close()
+            if world == 1 and not a.no_cpu_baseline:
+                handeye[name]["cpu_baseline"] = handeye_cpu_baseline(q, x0, 20 if moving else 5)
 
     # ---- batched homography refinement, one LM problem per view of config 4 ----
     homography = toolba = None
@@ -495,11 +590,16 @@ def main():
             nonzero = 2.0 * 6 * V * cols * (cols + 1) / 2
             issued = 512.0 * geo["tile_pairs"] * 6 * V
             roof.update({
-                "algorithmic_nonzero_per_launch": nonzero, "frac_nonzero": nonzero / t_s / 1e12 / peak,
+                # the headline fraction counts NON-ZERO work only: a view's Z row is zero outside its own camera's
+                # columns, so the blocks between different cameras' columns are structural zeros the kernel never issues
+                "achieved": nonzero / t_s / 1e12, "frac": nonzero / t_s / 1e12 / peak, "algorithmic_per_launch": nonzero,
+                "algorithmic_dense_triangle_per_launch": amount, "achieved_dense_triangle": amount / t_s / 1e12,
+                "frac_dense_triangle": amount / t_s / 1e12 / peak,
                 "issued_per_launch": issued, "frac_issued": issued / t_s / 1e12 / peak,
-                "note": "frac counts the upper triangle of all %d columns (SURVEY.md 8d); frac_nonzero leaves out the "
-                        "blocks between different cameras' columns, which are zero by structure; frac_issued is what "
-                        "the MFMA pipe executes: %d blocks of 16x16 per 4 rows" % (ns + 1, geo["tile_pairs"])})
+                "note": "frac: upper triangle of the %d columns a view's Z row is non-zero in (own camera + points + "
+                        "gradient); frac_dense_triangle: SURVEY.md 8(d)'s figure, the upper triangle of all %d columns, "
+                        "which counts structural zeros; frac_issued: what the MFMA pipe executes, %d blocks of 16x16 per "
+                        "4 rows" % (cols, ns + 1, geo["tile_pairs"])})
         # the iteration as a whole against the fp64 peak: SURVEY.md 8(d) flops per step (1 100 per observation on the
         # vector ALU + the symmetric half of the Schur contraction, 6 ns^2 per view) / wall time per step
         step_flops = 1100.0 * N + 6.0 * ns * ns * V
@@ -535,6 +635,25 @@ def main():
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": EVAL_BYTES_PER_OBS * N / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
+        # every phase of the iteration: time per launch and per iteration (hipEvent pairs of the phase pass), its
+        # algorithmic work and the fraction of the roofline that bounds it
+        kern = {}
+        names = {"schur": "k_schur_syrk4", "normal_eq": "k_normal_eq", "assemble": "k_reduce_all + k_assemble",
+                 "backsubst": "k_backsubst_cost_step", "cost": "k_final_scalars", "solve": "k_chol_step x %d" % geo.get("tile_columns", 0)}
+        for k, (bnd, amt, un, pk, sc) in work.items():
+            if k == "schur":
+                amt = roof.get("algorithmic_per_launch", amt) if dom == "schur" else amt
+            ms_it = per_iter.get(k, 0.0)
+            ms_l = per_launch.get(k, 0.0) if k == "schur" else ms_it
+            kern[k] = {"kernel": names[k], "us_per_iteration": 1e3 * ms_it, "share_of_device_time": ms_it / max(sum(per_iter.values()), 1e-30),
+                       "bound": bnd, "algorithmic": amt, "achieved": (amt / (ms_l * 1e-3) / sc) if ms_l > 0 else 0.0, "unit": un,
+                       "peak": pk, "frac": (amt / (ms_l * 1e-3) / sc / pk) if ms_l > 0 else 0.0}
+        out["kernels"] = kern
+        out["host_and_gaps_us_per_step"] = 1e3 * (1e3 * dt / a.steps - sum(per_iter.values()))
+        if configs is not None:
+            out["configs"] = configs
+        if config5_strong is not None:
+            out["config5_strong"] = config5_strong
         out["full_refine_to_convergence"] = full
         out["inner_iterations"] = inner
         out["handeye"] = handeye

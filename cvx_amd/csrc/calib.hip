@@ -1240,7 +1240,7 @@ extern "C" int cvx_calib_phase_times(cvx_calib *h, double ms[16]) {
 extern "C" int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]) {
     if (!h || !out) return CVX_ERR_INVALID_ARG;
     out[0] = h->ZC; out[1] = h->ns; out[2] = h->n_groups; out[3] = h->n_chunks; out[4] = h->nblk;
-    out[5] = h->T; out[6] = 6LL * h->V; out[7] = 0;
+    out[5] = h->T; out[6] = 6LL * h->V; out[7] = h->ns > 0 ? h->nT : 0;
     return CVX_OK;
 }
 

@@ -3,7 +3,10 @@
 // "X rebuilt" (/root/reference/modules/calib/src/handeye.cpp:282-324).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -24,6 +27,8 @@ struct cvx_handeye {
     double *d_pairs = nullptr, *d_p7 = nullptr, *d_partial = nullptr, *d_out = nullptr;
     double *h_out = nullptr, *h_p7 = nullptr;
     double *d_eval = nullptr;
+    long long lm_seq = 0;
+    HeLmOut *d_lm = nullptr, *h_lm = nullptr;    // result of the one-launch solve (k_he_lm): host-mapped, made on first use
     // exchange
     cvx_allreduce_fn xfn = nullptr;
     void *xctx = nullptr;
@@ -34,6 +39,7 @@ struct cvx_handeye {
             if (p) (void)hipFree(p);
         if (h_out) (void)hipHostFree(h_out);
         if (h_p7) (void)hipHostFree(h_p7);
+        if (h_lm) (void)hipHostFree(h_lm);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -106,6 +112,54 @@ int device_normal_eq(cvx_handeye *h, const double p[7], double H[36], double g[6
         for (int b = a; b < 6; ++b) { H[a * 6 + b] = h->h_out[e]; H[b * 6 + a] = h->h_out[e]; ++e; }
     for (int a = 0; a < 6; ++a) g[a] = h->h_out[21 + a];
     *cost = 0.5 * h->h_out[27];
+    return CVX_OK;
+}
+
+// the whole trust-region solve in one launch (k_he_lm): problems of at most HE_LM_MAX_PAIRS pairs on one rank
+int device_lm(cvx_handeye *h, double p[7], const cvx_lm_options &opt, cvx_lm_summary &sum) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::memset(&sum, 0, sizeof sum);
+    if (!h->h_lm) {
+        // the kernel writes its result straight into pinned host memory (posted writes, 33 KB at most): one
+        // synchronisation and no copy between the launch and the answer
+        CVX_HIP(hipHostMalloc((void **)&h->h_lm, sizeof(HeLmOut), hipHostMallocMapped));
+        CVX_HIP(hipHostGetDevicePointer((void **)&h->d_lm, h->h_lm, 0));
+        h->h_lm->seq = 0;
+    }
+    HeLmStart start;
+    std::memcpy(start.p, p, sizeof start.p);
+    start.seq = ++h->lm_seq;
+    const int threads = (int)std::min<long long>(HE_LM_MAX_THREADS, std::max<long long>(64, (h->n + 63) / 64 * 64));
+    hipLaunchKernelGGL(k_he_lm, dim3(1), dim3(threads), 0, h->stream, PlaneSrc{h->d_pairs, h->n}, start, opt, h->d_lm);
+    CVX_HIP(hipGetLastError());
+    // the result is polled (a stream synchronisation's wake-up costs more than the solve's first iterations)
+    {
+        volatile const long long *flag = &h->h_lm->seq;
+        const auto tp = std::chrono::steady_clock::now();
+        long long spins = 0;
+        while (*flag != start.seq) {
+            if ((++spins & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count() > 30.0) {
+                CVX_HIP(hipStreamSynchronize(h->stream));       // surfaces a kernel fault as a HIP error
+                if (*flag != start.seq) { cvx::set_last_error("hand-eye solve result never arrived in host memory"); return CVX_ERR_HIP; }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    const HeLmOut &r = *h->h_lm;
+    if (r.status) return r.status;
+    const int len = std::min(std::max(r.trace_len, 0), CVX_TRACE_MAX);
+    std::memcpy(p, r.p, 7 * sizeof(double));
+    sum.iterations = r.iterations; sum.num_successful = r.num_successful; sum.num_linear_solves = r.num_linear_solves;
+    sum.termination = r.termination; sum.initial_cost = r.initial_cost; sum.final_cost = r.final_cost;
+    sum.trace_len = len;
+    std::memcpy(sum.trace_cost, r.trace[0], len * sizeof(double));
+    std::memcpy(sum.trace_accepted, r.trace[1], len * sizeof(double));
+    std::memcpy(sum.trace_damping, r.trace[2], len * sizeof(double));
+    std::memcpy(sum.trace_gradient, r.trace[3], len * sizeof(double));
+#ifdef HE_LM_PROF
+    sum.trace_gradient[1000] = r.trace[3][1000]; sum.trace_gradient[1001] = r.trace[3][1001];      // 100 MHz ticks: evaluations | scalar sections
+#endif
+    sum.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return CVX_OK;
 }
 
@@ -365,6 +419,11 @@ extern "C" int cvx_handeye_solve(cvx_handeye *h, double p[7], const cvx_lm_optio
         return CVX_ERR_UNSUPPORTED;
     }
     CVX_HIP(hipSetDevice(h->device));
+    // strategy 0 on one rank, up to HE_LM_MAX_PAIRS pairs: the whole loop runs on the device in one launch;
+    // CVX_HANDEYE_HOST_LOOP=1 keeps the host-driven loop (the same control flow, lm_driver.cpp), as the tests compare
+    const char *hl = std::getenv("CVX_HANDEYE_HOST_LOOP");
+    const bool host_loop = hl && hl[0] == '1';
+    if (opt->strategy == 0 && h->nranks == 1 && h->n <= HE_LM_MAX_PAIRS && !host_loop) return device_lm(h, p, *opt, *summary);
     HandEyeEvaluator ev(h, p);
     int st = cvx::lm_minimize(ev, *opt, *summary);
     std::memcpy(p, ev.x, 7 * sizeof(double));

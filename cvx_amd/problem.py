@@ -113,7 +113,7 @@ class Calib:
         g = (C.c_int64 * 8)()
         check(lib().cvx_calib_geometry(self.h, g), "geometry")
         return {"ZC": g[0], "ns": g[1], "n_groups": g[2], "n_chunks": g[3], "tile_pairs": g[4], "threads": g[5],
-                "z_rows": g[6]}
+                "z_rows": g[6], "tile_columns": g[7]}
 
 
 def inner_ordering(cam_of_view, view_off, point_id, n_cameras, n_points, fix_intrinsics=False, fix_points=False):

@@ -224,7 +224,8 @@ int cvx_calib_time_schur(cvx_calib *h, int reps, double *ms_per_launch);
 
 /* launch geometry, for stating algorithmic work: [0] Z columns, [1] reduced-system size,
  * [2] normal-equation workgroups, [3] Schur row chunks, [4] 16x16 blocks of the upper triangle of Z^T Z,
- * [5] threads per normal-equation workgroup, [6] Z rows (6 * n_views) */
+ * [5] threads per normal-equation workgroup, [6] Z rows (6 * n_views), [7] 32-column tile columns of the reduced
+ * solve (launches of k_chol_step per LM iteration) */
 int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]);
 
 /* ------------------------------------------------------------------------ */
@@ -260,6 +261,10 @@ int cvx_handeye_normal_eq_static(int n_pairs, const double *d_qa, const double *
                                  const double *d_tb, const double *d_p7, double *d_out, int device, void *stream);
 int cvx_handeye_set_exchange(cvx_handeye *h, cvx_allreduce_fn fn, void *ctx, int rank, int nranks,
                              int device_buffers);
+/* solveNonLinear's ceres::Solve (handeye.cpp:310-322): p in-out.  Strategy 0 on one rank with at most 512 motion
+ * pairs runs as ONE kernel launch (the whole trust-region loop on the device; same decisions as the host-driven loop,
+ * which larger problems, view-sharded handles and strategy 1 take; CVX_HANDEYE_HOST_LOOP=1 in the environment forces
+ * the host loop).  opt->inner_iterations is refused with CVX_ERR_UNSUPPORTED (one parameter block pair). */
 int cvx_handeye_solve(cvx_handeye *h, double p[7], const cvx_lm_options *opt, cvx_lm_summary *summary);
 
 /* ------------------------------------------------------------------------ */

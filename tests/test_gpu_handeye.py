@@ -109,3 +109,56 @@ def test_edge_cases():
         H, gr, c = g.normal_eq(x0); Ho, go, co = o.normal_eq(x0)
         assert rel_err(H, Ho) < 1e-12 and rel_err(gr, go) < 1e-12 and abs(c - co) <= 1e-13 * co
         g.close()
+
+
+@pytest.mark.parametrize("n_poses,moving,nonmono", [(200, True, 0), (30, False, 0), (32, False, 1), (3, True, 0)])
+def test_one_launch_solve_equals_the_host_driven_loop_and_the_oracle(orc, monkeypatch, n_poses, moving, nonmono):
+    """cvx_handeye_solve runs problems of up to 512 pairs as ONE launch (k_he_lm: the whole trust-region loop on the
+    device).  It restates lm_driver.cpp's strategy 0, so it must take the same decisions as the host-driven loop over
+    the multi-workgroup kernels (CVX_HANDEYE_HOST_LOOP=1) and as the oracle: iteration count, termination, accept /
+    reject trace, costs to 1e-12, X to 1e-12 -- one wave and several, non-monotonic steps, and a near-degenerate two-pair
+    problem included."""
+    g, o, q, xg, x0 = make(n_poses, 77 + n_poses, moving, orc)
+    assert g.n <= 512
+    og, oo = capi.options("handeye"), orc.options("handeye")
+    og.nonmonotonic = oo.nonmonotonic = nonmono
+    p, s = g.solve(x0, og)
+    monkeypatch.setenv("CVX_HANDEYE_HOST_LOOP", "1")
+    ph, sh = g.solve(x0, og)
+    monkeypatch.delenv("CVX_HANDEYE_HOST_LOOP")
+    po, so = o.solve(x0, oo)
+    for other, ps in ((sh, ph), (so, po)):
+        assert (s.iterations, s.termination, s.num_successful, s.num_linear_solves) == (
+            other.iterations, other.termination, other.num_successful, other.num_linear_solves)
+        assert s.trace_len == other.trace_len
+        a, b = s.trace(), other.trace()
+        assert np.array_equal(a["accepted"], b["accepted"])
+        assert np.all(np.abs(a["cost"] - b["cost"]) <= 1e-12 * np.abs(b["cost"]))
+        assert np.all(np.abs(a["damping"] - b["damping"]) <= 1e-9 * b["damping"])
+        assert abs(s.initial_cost - other.initial_cost) <= 1e-13 * other.initial_cost
+        assert abs(s.final_cost - other.final_cost) <= 1e-12 * other.final_cost
+        assert np.max(np.abs(p - ps)) <= 1e-12
+    # repeated runs: the same bits
+    p2, s2 = g.solve(x0, og)
+    assert np.array_equal(p, p2) and s2.final_cost == s.final_cost
+    g.close()
+
+
+def test_one_launch_solve_iteration_limit_and_tolerances(orc):
+    """max_iterations ends the device loop (with Ceres' gradient test after the last accepted step), and tolerances
+    switched off run every iteration asked -- what bench.py times"""
+    g, o, q, xg, x0 = make(200, 20260002, True, orc)
+    for k in (1, 3, 20):
+        og, oo = capi.options("handeye"), orc.options("handeye")
+        for x in (og, oo):
+            x.function_tolerance = x.gradient_tolerance = x.parameter_tolerance = -1.0
+            x.max_iterations = k
+        p, s = g.solve(x0, og)
+        po, so = o.solve(x0, oo)
+        # (long after convergence accept / reject is decided by the last bits, and a run of rejections may take the
+        #  radius below its minimum in the last iteration: termination 5 instead of 4)
+        assert s.iterations == so.iterations == k and s.termination in (4, 5) and so.termination in (4, 5)
+        if k < 20:
+            assert s.termination == so.termination == 4
+        assert abs(s.final_cost - so.final_cost) <= 1e-12 * so.final_cost and np.max(np.abs(p - po)) <= 1e-12
+    g.close()

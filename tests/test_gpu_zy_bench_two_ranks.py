@@ -21,7 +21,7 @@ def _run(scaling):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--no-cpu-baseline", "--scaling", scaling]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=100)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                      # rank 0 alone reports
@@ -41,9 +41,17 @@ def test_two_rank_bench_line_strong_scaling():
     assert abs(d["value"] - 1080000 * 4 / (d["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * d["value"]
     # the sharded solve walks the same path as the single-GPU one: same accepted steps, same cost to ~1e-10
     assert d["config"]["accepted_steps_in_last_solve"] >= 1
+    # north_star's config 5 as a strong-scaling block of the same line: the 100 000-view problem over both ranks
+    c5 = d["config5_strong"]
+    assert c5["observations"] == 10800000 and c5["pose_blocks"] == 100000 and c5["views_this_rank"] == 50000
+    assert c5["steps"] == 20 and c5["n_gpus"] == 2 and c5["scaling"] == "strong" and c5["shared_unknowns"] == 388
+    assert abs(c5["value"] - 10800000 * 20 / c5["seconds"]) <= 1e-6 * c5["value"]
+    assert c5["cost"][1] < 1e-3 * c5["cost"][0]                 # the sharded iterations do converge
+    assert "configs" not in d                                   # the one-GPU blocks stay out of the N > 1 line
 
 
 def test_two_rank_bench_line_weak_scaling():
     d = _run("weak")
     assert d["config"]["observations_total"] == 2 * 1080000 and d["config"]["observations_rank0"] == 1080000
     assert abs(d["value"] - 2 * 1080000 * 4 / (d["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * d["value"]
+    assert d["config5_strong"]["observations"] == 10800000      # config 5 is cut over the ranks in either mode
