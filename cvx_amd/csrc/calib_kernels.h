@@ -369,8 +369,11 @@ struct K2Args {
     double *Z, *Lfac, *Dv, *gv, *s2pose_out, *slab_pt, *slab_cam, *grp_scal;
 };
 
+#ifndef K2_MIN_WAVES
+#define K2_MIN_WAVES 2
+#endif
 template <int T, int MODE, bool ALIGNED>
-__global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
+__global__ void __launch_bounds__(T, K2_MIN_WAVES) k_normal_eq(K2Args a) {
     extern __shared__ double lds[];
     constexpr int W = T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -440,6 +443,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
         }
         K2_STAMP(0);
         // ---- per-point accumulators (unique point ids inside a view: plain read-modify-write) ----
+#ifndef K2_NO_PACC
         if (active && a.pts_free) {
             // pa[i] += Jc[c] Jx[b] + Jc[9 + c] Jx[3 + b] etc., as two fused multiply-adds per accumulator (x row, then y row)
             double *pa = ALIGNED ? pacc : accpt + pid * PT_ACC;
@@ -459,6 +463,7 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
             pa[34] = acc_fma(Jx[4], r[1], acc_fma(Jx[1], r[0], pa[34]));
             pa[35] = acc_fma(Jx[5], r[1], acc_fma(Jx[2], r[0], pa[35]));
         }
+#endif
         K2_STAMP(1);
         // ---- Gram of the staged rows on the matrix cores ----
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -577,7 +582,11 @@ __global__ void __launch_bounds__(T, 2) k_normal_eq(K2Args a) {
 #endif
     // ---- flush the group's accumulators ----
     double *sp = a.slab_pt + (size_t)g * a.P * PT_ACC;
+#ifdef K2_NO_PACC
+    if (false) {
+#else
     if (a.pts_free) {
+#endif
         if (ALIGNED) {
             // points the group never sees keep the zeros the slab was created with
             if (v0 < v1 && tid < a.view_off[v0 + 1] - a.view_off[v0]) {

@@ -25,116 +25,77 @@ static int lm_trust_region(Evaluator &ev, const cvx_lm_options &o, cvx_lm_summar
     InitInfo ini = ev.init(o.jacobi_scaling != 0);
     if (ini.status) return ini.status;
     if (!std::isfinite(ini.cost)) return CVX_ERR_NUMERIC;
-    double cost = ini.cost;
-    sum.initial_cost = cost;
-    double gmax = ini.grad_max;
-    double radius = o.initial_radius, decrease_factor = 2.0;
-    // TrustRegionStepEvaluator
-    double ev_min = cost, ev_cur = cost, ev_ref = cost, ev_cand = cost, ev_acc_ref = 0, ev_acc_cand = 0;
-    int ev_nonmono = 0;
-    const int max_nonmono = o.nonmonotonic ? o.max_consecutive_nonmonotonic_steps : 0;
-    int term = 0, invalid_run = 0, it = 0;
-    bool need_gcheck = false;   // the gradient at the current point has not been tested yet
-    bool inner_enabled = o.inner_iterations != 0;
-    // lowest-cost point visited: the current one until an uphill step is accepted
-    double best_cost = cost;
-    bool best_is_current = true;
-    if (gmax <= o.gradient_tolerance) term = 1;
+    sum.initial_cost = ini.cost;
+    // the decisions themselves are trust_region.h's (shared with the device: speculated steps of the calibration path)
+    TrOptions to;
+    to.max_iterations = o.max_iterations;
+    to.max_nonmono = o.nonmonotonic ? o.max_consecutive_nonmonotonic_steps : 0;
+    to.function_tolerance = o.function_tolerance; to.gradient_tolerance = o.gradient_tolerance;
+    to.parameter_tolerance = o.parameter_tolerance;
+    to.max_radius = o.max_radius; to.min_radius = o.min_radius; to.min_relative_decrease = o.min_relative_decrease;
+    TrState t;
+    tr_init(t, ini.cost, ini.grad_max, o.initial_radius, o.inner_iterations != 0);
+    if (t.gmax <= o.gradient_tolerance) t.term = 1;
 
-    while (!term) {
-        if (it >= o.max_iterations) {
-            if (need_gcheck) {   // Ceres tests the gradient right after the accepted step
+    while (!t.term) {
+        if (t.it >= o.max_iterations) {
+            if (t.need_gcheck) {   // Ceres tests the gradient right after the accepted step
                 cvx_damping d0 = {0, 0, 0, 0};
                 StepInfo g = ev.try_step(d0, o.gradient_tolerance, true);
                 if (g.status) return g.status;
-                if (g.grad_converged) { term = 1; break; }
+                if (g.grad_converged) { t.term = 1; break; }
             }
-            term = 4;
+            t.term = 4;
             break;
         }
-        cvx_damping d = {1.0 / radius, 0.0, o.min_lm_diagonal, o.max_lm_diagonal};
-        StepInfo s = ev.try_step(d, need_gcheck ? o.gradient_tolerance : -1.0, false);
+        cvx_damping d = {1.0 / t.radius, 0.0, o.min_lm_diagonal, o.max_lm_diagonal};
+        ev.lm_state(t, to, d);
+        StepInfo s = ev.try_step(d, t.need_gcheck ? o.gradient_tolerance : -1.0, false);
         if (s.status) return s.status;
-        if (s.grad_converged) { term = 1; break; }
-        need_gcheck = false;
-        gmax = s.grad_max;
-        ++it;
-        sum.num_linear_solves++;
-        if (!s.ok || !(s.model_change > 0.0)) {
-            // HandleInvalidStep + LevenbergMarquardtStrategy::StepIsInvalid
-            trace_push(sum, NAN, 0, radius, gmax);
-            if (++invalid_run >= 5) { term = 6; break; }
-            radius *= 0.5;
-            continue;
-        }
-        invalid_run = 0;
+        TrStep st;
+        st.grad_converged = s.grad_converged; st.ok = s.ok; st.grad_max = s.grad_max; st.cand_cost = s.cand_cost;
+        st.model_change = s.model_change; st.step_norm2 = s.step_norm2; st.x_norm2 = s.x_norm2;
+        TrTrace tr;
+        int what = tr_begin_step(t, st, tr);
+        if (tr.push) trace_push(sum, tr.cost, tr.accepted, tr.damping, tr.grad);
+        if (what != TR_GO_ON) continue;         // stopped (the loop condition sees it) or an invalid step: next try
         double cand = s.cand_cost, model_change = s.model_change, step_norm2 = s.step_norm2;
-        bool inner_useful = false;
-        if (inner_enabled && std::isfinite(cand)) {
+        int inner_useful = 0;
+        if (t.inner_enabled && std::isfinite(cand)) {
             // TrustRegionMinimizer::DoInnerIterationsIfNeeded: what the pass gains is credited to the model, and
             // the passes stop for good once one gains less than the tolerance
             double inner_cost = 0, n2 = 0;
-            const int st = ev.inner_iterations(&inner_cost, &n2);
-            if (st) return st;
+            const int ist = ev.inner_iterations(&inner_cost, &n2);
+            if (ist) return ist;
             sum.num_inner_iteration_steps++;
             model_change += cand - inner_cost;
-            inner_useful = inner_cost < cost;
-            inner_enabled = (1.0 - inner_cost / cand) > o.inner_iteration_tolerance;
+            inner_useful = inner_cost < t.cost;
+            t.inner_enabled = (1.0 - inner_cost / cand) > o.inner_iteration_tolerance;
             cand = inner_cost;
             step_norm2 = n2;
         }
-        const double sn = std::sqrt(step_norm2), xn = std::sqrt(s.x_norm2);
-        if (sn <= o.parameter_tolerance * (xn + o.parameter_tolerance)) {
-            trace_push(sum, cand, 0, radius, gmax);
-            term = 2;
-            break;
-        }
-        if (std::fabs(cost - cand) <= o.function_tolerance * cost) {
-            trace_push(sum, cand, 0, radius, gmax);
-            term = 3;
-            break;
-        }
-        const double rel = (ev_cur - cand) / model_change;
-        const double hist = (ev_ref - cand) / (ev_acc_ref + model_change);
-        const double rho = (max_nonmono > 0 && hist > rel) ? hist : rel;
-        if (inner_useful || rho > o.min_relative_decrease) {      // IsStepSuccessful
-            trace_push(sum, cand, 1, radius, gmax);
-            if (cand < best_cost) {
-                best_cost = cand; best_is_current = true;
-            } else if (best_is_current) {
+        int save_best = 0;
+        what = tr_finish_step(t, to, cand, model_change, step_norm2, s.x_norm2, inner_useful, tr, &save_best);
+        if (tr.push) trace_push(sum, tr.cost, tr.accepted, tr.damping, tr.grad);
+        if (what == TR_ACCEPTED) {
+            if (save_best) {
                 int sb = ev.save_best();
                 if (sb) return sb;
-                best_is_current = false;
             }
-            int st = ev.accept();
-            if (st) return st;
-            cost = cand;
-            double t = 2.0 * rho - 1.0;
-            double f = 1.0 - t * t * t;
-            if (f < 1.0 / 3.0) f = 1.0 / 3.0;
-            radius = radius / f;
-            if (radius > o.max_radius) radius = o.max_radius;
-            decrease_factor = 2.0;
-            ev_cur = cand; ev_acc_cand += model_change; ev_acc_ref += model_change;
-            if (ev_cur < ev_min) { ev_min = ev_cur; ev_nonmono = 0; ev_cand = ev_cur; ev_acc_cand = 0; }
-            else { ++ev_nonmono; if (ev_cur > ev_cand) { ev_cand = ev_cur; ev_acc_cand = 0; } }
-            if (ev_nonmono == max_nonmono) { ev_ref = ev_cand; ev_acc_ref = ev_acc_cand; }
-            sum.num_successful++;
-            need_gcheck = true;
-        } else {
-            trace_push(sum, cand, 0, radius, gmax);
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
-            if (radius < o.min_radius) { term = 5; break; }
+            int ast = ev.accept();
+            if (ast) return ast;
         }
     }
-    if (!best_is_current) {
+    double cost = t.cost;
+    if (!t.best_is_current) {
         int rb = ev.restore_best();
         if (rb) return rb;
-        cost = best_cost;
+        cost = t.best_cost;
     }
-    sum.iterations = it;
-    sum.termination = term;
+    sum.iterations = t.it;
+    sum.num_successful = t.num_successful;
+    sum.num_linear_solves = t.num_linear_solves;
+    sum.termination = t.term;
     sum.final_cost = cost;
     return CVX_OK;
 }

@@ -12,6 +12,7 @@
 //               /root/reference/modules/util/src/3rdparty/levmar/lm_core.c:163-409.
 #pragma once
 #include "../../include/cvx_amd.h"
+#include "trust_region.h"
 
 namespace cvx {
 
@@ -55,6 +56,9 @@ public:
     virtual int restore_best() = 0;
     // One inner-iteration pass (CoordinateDescentMinimizer::Minimize) on the last candidate, in place: *cost = its
     // cost afterwards, *step_norm2 = |x - candidate|^2 afterwards.  Evaluators without one refuse.
+    // Strategy 0 tells the evaluator, right before every try_step that solves a linear step, the loop's state and the
+    // damping it is about to ask for (an evaluator may use it to run the loop's decisions ahead of the host: calib.hip)
+    virtual void lm_state(const TrState &, const TrOptions &, const cvx_damping &) {}
     virtual int inner_iterations(double *cost, double *step_norm2) { (void)cost; (void)step_norm2; return CVX_ERR_UNSUPPORTED; }
 };
 
