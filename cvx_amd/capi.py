@@ -119,6 +119,7 @@ SIGNATURES = {
     "cvx_calib_phase_times": (C.c_int, [C.c_void_p, dp]),
     "cvx_calib_time_schur": (C.c_int, [C.c_void_p, C.c_int, dp]),
     "cvx_calib_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "cvx_calib_speculation_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "cvx_handeye_create": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "cvx_handeye_destroy": (None, [C.c_void_p]),
     "cvx_handeye_cost": (C.c_int, [C.c_void_p, dp, dp]),

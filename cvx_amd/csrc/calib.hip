@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -68,6 +69,11 @@ struct cvx_calib {
     // device: parameters (current / candidate)
     double *d_intr[2] = {nullptr, nullptr}, *d_points[2] = {nullptr, nullptr}, *d_poses[2] = {nullptr, nullptr};
     int cur = 0;
+    // the two buffers of each kind are one allocation, buffer 1 `*_step` doubles behind buffer 0 (multiples of 32), so
+    // that a speculated step's kernels can pick the current one from a device-side index (LmDev::cur)
+    long long intr_step = 0, points_step = 0, poses_step = 0, rt_step = 0;
+    LmDev *d_lm = nullptr, *h_lm = nullptr;      // the speculated steps' record and its pinned staging copy
+    long long n_spec_used = 0, n_spec_dropped = 0;   // speculated steps the loop went on to use / that were switched off
     // device: work
     double *d_rt[2] = {nullptr, nullptr};   // per-view R, dR/dw, t of the current / candidate poses
     bool rt_valid[2] = {false, false};
@@ -123,8 +129,7 @@ struct cvx_calib {
 cvx_calib::~cvx_calib() {
     (void)hipSetDevice(device);
     void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
-                    d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_intr[1], d_points[0], d_points[1], d_poses[0],
-                    d_poses[1], d_rt[0], d_rt[1], d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
+                    d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_points[0], d_poses[0], d_rt[0], d_lm, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
     for (void *p : ptrs)
@@ -132,6 +137,7 @@ cvx_calib::~cvx_calib() {
     if (h_E) (void)hipHostFree(h_E);
     if (h_ds_emb) (void)hipHostFree(h_ds_emb);
     if (h_E2) (void)hipHostFree(h_E2);
+    if (h_lm) (void)hipHostFree(h_lm);
     if (h_ib_active) (void)hipHostFree(h_ib_active);
     if (ev_made)
         for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
@@ -165,8 +171,15 @@ int launch_normal_eq(cvx_calib *h, const K2Args &a) {
     dim3 grid(h->n_groups);
 #define CVX_LAUNCH(TT, AL)                                                                                    \
     do {                                                                                                      \
-        CVX_HIP(hipFuncSetAttribute((const void *)k_normal_eq<TT, MODE, AL>,                                  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds));             \
+        /* the limit is per function and process: raised when this handle needs more than any before it (the   \
+           call sits on the host's path between a step's result and the next step's first launch) */          \
+        static std::atomic<size_t> lds_limit[16];                                                             \
+        std::atomic<size_t> &lim = lds_limit[h->device & 15];                                                 \
+        if (h->k2_lds > lim.load(std::memory_order_relaxed)) {                                                \
+            CVX_HIP(hipFuncSetAttribute((const void *)k_normal_eq<TT, MODE, AL>,                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds));         \
+            lim.store(h->k2_lds, std::memory_order_relaxed);                                                  \
+        }                                                                                                     \
         hipLaunchKernelGGL((k_normal_eq<TT, MODE, AL>), grid, dim3(TT), h->k2_lds, h->stream, a);             \
     } while (0)
 #define CVX_CASE(TT)                                                      \
@@ -187,7 +200,7 @@ int launch_normal_eq(cvx_calib *h, const K2Args &a) {
     return CVX_OK;
 }
 
-K2Args make_k2(cvx_calib *h, const cvx_damping &d) {
+K2Args make_k2(cvx_calib *h, const cvx_damping &d, bool spec = false) {
     K2Args a;
     a.view_off = h->d_view_off; a.cam_of_view = h->d_cam_of_view; a.point_id = h->d_point_id;
     a.obs_x = h->d_obs_x; a.obs_y = h->d_obs_y;
@@ -197,6 +210,10 @@ K2Args make_k2(cvx_calib *h, const cvx_damping &d) {
     a.inv_radius = d.inv_radius; a.mu = d.mu; a.min_diag = d.min_diag; a.max_diag = d.max_diag;
     a.Z = h->d_Z; a.Lfac = h->d_Linv; a.Dv = h->d_Dv; a.gv = h->d_gv; a.s2pose_out = nullptr;
     a.slab_pt = h->d_slab_pt; a.slab_cam = h->d_slab_cam; a.grp_scal = h->d_grp_scal;
+    a.st = nullptr; a.intr_step = h->intr_step; a.points_step = h->points_step; a.rt_step = h->rt_step;
+    if (spec) {         // buffer 0's pointers: the kernel picks the current buffer and the damping from the record
+        a.st = h->d_lm; a.intr = h->d_intr[0]; a.points = h->d_points[0]; a.rt = h->d_rt[0];
+    }
     return a;
 }
 
@@ -234,10 +251,12 @@ int launch_schur(cvx_calib *h) {
     return CVX_OK;
 }
 
-int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_scale) {
-    int st = launch_pose_prepare(h, h->cur);
+// spec: a speculated step (calib_kernels.h, LmDev) -- the current point's tables are there by construction (the step
+// before made its candidate's), K2 and the assembly read the record
+int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_scale, bool spec = false) {
+    int st = spec ? CVX_OK : launch_pose_prepare(h, h->cur);
     if (st) return st;
-    K2Args a = make_k2(h, d);
+    K2Args a = make_k2(h, d, spec);
     ph_begin(h, PH_NORMAL);
     if (init_mode) {
         a.s2pose_out = write_scale ? h->d_s2pose : nullptr;
@@ -287,6 +306,7 @@ int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_sca
         s.A = h->A_ready ? h->d_A : nullptr; s.Ds = h->d_Ds; s.s2 = h->d_s2sh; s.npad = h->npad;
         s.inv_radius = d.inv_radius; s.mu = d.mu; s.min_diag = d.min_diag; s.max_diag = d.max_diag;
         s.X = (h->nranks > 1) ? h->d_X : nullptr; s.n_scal = 2 + 2 * h->nranks;
+        s.st = spec ? h->d_lm : nullptr;
         const long long pitch = h->A_ready ? h->npad : h->ns;
         const long long n = pitch * pitch + h->ns;
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, s);
@@ -636,19 +656,23 @@ public:
         }
         out.status = run_step(d);
         if (out.status) return out;
-        const double *R = h->h_E2;
-        out.cost = 0.5 * R[11];
-        out.grad_max = std::max(R[9], R[13]);
-        if (out.grad_max <= gtol) { out.grad_converged = true; return out; }
-        if (gradient_only) return out;
-        if (R[12] > 0 || R[8] > 0) { out.ok = false; return out; }
-        out.cand_cost = 0.5 * R[0];
-        out.model_change = 0.5 * (R[1] + R[4]);
-        out.step_norm2 = R[2] + R[5];
-        out.x_norm2 = R[3] + R[6];
-        out.free_norm2 = R[3] + R[7];
-        out.ok = std::isfinite(out.model_change) && std::isfinite(out.step_norm2);
+        // (the same reading of the step's 16 doubles as the device's: step_from_record)
+        const cvx::TrStep ts = step_from_record(rec, gtol, &out.cost);
+        out.grad_max = ts.grad_max;
+        if (ts.grad_converged) { out.grad_converged = true; return out; }
+        out.ok = ts.ok != 0;
+        if (!out.ok && (rec[12] > 0 || rec[8] > 0)) return out;
+        out.cand_cost = ts.cand_cost;
+        out.model_change = ts.model_change;
+        out.step_norm2 = ts.step_norm2;
+        out.x_norm2 = ts.x_norm2;
+        out.free_norm2 = rec[3] + rec[7];
         return out;
+    }
+
+    // strategy 0's state right before the try_step that follows: what a speculated step's record starts from
+    void lm_state(const cvx::TrState &t, const cvx::TrOptions &o, const cvx_damping &d) override {
+        snap_tr = t; snap_opt = o; snap_d = d; have_snap = true;
     }
 
     int accept() override {
@@ -709,10 +733,34 @@ public:
     }
 
 private:
-    // the whole linear step on the device: linearise, damp + factor + solve the reduced system, form the
-    // candidate, back-substitute the poses, evaluate the candidate; one 16-double copy comes back
-    int run_step(const cvx_damping &d) {
-        int st = linearize(h, d, false, false);
+    // ---- speculated steps (calib_kernels.h, LmDev) ----
+    cvx::TrState snap_tr;
+    cvx::TrOptions snap_opt;
+    cvx_damping snap_d = {0, 0, 0, 0};
+    bool have_snap = false;
+    bool spec_inflight = false;      // the NEXT step's kernels are enqueued already
+    bool spec_runs = false;          // ... and the device said they would run
+    long long spec_seq = 0;
+    const double *rec = nullptr;     // the 16 doubles of the last step (host memory)
+
+    // Opt-in (CVX_CALIB_SPECULATE=1 in the environment): measured on the box, the host's turn-around between two steps
+    // is ~6 us, and taking the decision on the device puts ~9.5 us of its own on the critical path (the decision in the
+    // last kernel 3.7 us, the candidate's rotation tables 5.8 us that the host's turn-around used to hide): 0.408 vs
+    // 0.404 ms per iteration at config 4.  Otherwise: one rank, pose blocks present, strategy 0
+    // past its inner iterations, no timing or debug outputs asked.
+    bool can_speculate() const {
+        const char *e = std::getenv("CVX_CALIB_SPECULATE");
+        const bool on = e && e[0] == '1';
+        return on && have_snap && !snap_tr.inner_enabled && h->nranks == 1 && h->V > 0 && h->ns > 0 && !h->timing &&
+               h->d_E2_map && !want_S && !keep_dposes;
+    }
+
+    // all kernels of one linear step, enqueued: linearise, damp + factor + solve the reduced system, form the candidate,
+    // back-substitute the poses, evaluate the candidate, publish 16 doubles, the candidate's rotation tables.
+    // spec: every kernel that reads the point or the damping takes them from the record (and returns at once when the
+    // record says the step is off); the 16 doubles go to host record `seq & 1`.
+    int enqueue_step(const cvx_damping &d, bool spec, long long seq) {
+        int st = linearize(h, d, false, false, spec);
         if (st) return st;
         const int ns = h->ns, nxt = 1 - h->cur;
         ph_begin(h, PH_SOLVE);
@@ -741,6 +789,13 @@ private:
         f.intr = h->d_intr[h->cur]; f.points = h->d_points[h->cur];
         f.intr_cand = h->d_intr[nxt]; f.points_cand = h->d_points[nxt];
         f.ds_emb = h->d_ds_emb; f.delta_s = h->d_delta_s; f.R = h->d_E2;
+        f.st = nullptr; f.intr_step = h->intr_step; f.points_step = h->points_step; f.poses_step = h->poses_step;
+        const double *poses_cur = h->d_poses[h->cur];
+        double *poses_nxt = h->d_poses[nxt];
+        if (spec) {
+            f.st = h->d_lm; f.intr = h->d_intr[0]; f.points = h->d_points[0]; f.intr_cand = h->d_intr[0]; f.points_cand = h->d_points[0];
+            poses_cur = h->d_poses[0]; poses_nxt = h->d_poses[0];
+        }
         if (h->V == 0) {
             // no pose blocks: the step's bookkeeping is a kernel of its own
             if (h->fin_lds > 64 * 1024)
@@ -757,7 +812,7 @@ private:
             if (bsc_lds > 64 * 1024)
                 CVX_HIP(hipFuncSetAttribute((const void *)k_backsubst_cost_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bsc_lds));
             hipLaunchKernelGGL(k_backsubst_cost_step, dim3((h->V + 3) / 4), dim3(BSC_THREADS), bsc_lds, h->stream, h->d_Z,
-                               h->d_Linv, h->d_Dv, h->d_gv, h->d_cam_of_view, h->d_poses[h->cur], h->d_poses[nxt],
+                               h->d_Linv, h->d_Dv, h->d_gv, h->d_cam_of_view, poses_cur, poses_nxt,
                                keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V,
                                h->d_view_off, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_cost_view, f);
             CVX_HIP(hipGetLastError());
@@ -766,17 +821,22 @@ private:
         // one rank, no phase timing: the result lands in host-mapped memory and the host polls its sequence number
         // (several ranks with a device-buffer hook: the same, published by a small kernel behind the all-reduce)
         const bool sharded_dev = h->nranks > 1 && h->xfn && h->xdev;
-        const bool polled = (h->nranks == 1 || sharded_dev) && !h->timing && h->d_E2_map;
-        const double seq = (double)(++h->step_seq);
+        polled = (h->nranks == 1 || sharded_dev) && !h->timing && h->d_E2_map;
+        const double fseq = (double)seq;
         ph_begin(h, PH_COST);
-        hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V,
-                           h->d_out_view, h->V, h->d_E2, (polled && !sharded_dev) ? h->d_E2_map : (double *)nullptr, seq);
+        if (spec) {
+            hipLaunchKernelGGL(k_final_scalars_decide, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V, h->d_out_view, h->V,
+                               h->d_E2, h->d_E2_map + 32 * (seq & 1), fseq, h->d_lm);
+        } else {
+            hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V,
+                               h->d_out_view, h->V, h->d_E2, (polled && !sharded_dev) ? h->d_E2_map : (double *)nullptr, fseq);
+        }
         CVX_HIP(hipGetLastError());
         ph_end(h, PH_COST);
         if (sharded_dev) {
             if (h->xfn(h->xctx, h->d_E2, 4, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
             if (polled) {
-                hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, h->stream, h->d_E2, h->d_E2_map, seq);
+                hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, h->stream, h->d_E2, h->d_E2_map, fseq);
                 CVX_HIP(hipGetLastError());
             }
         }
@@ -785,18 +845,32 @@ private:
             CVX_HIP(hipEventRecord(h->ev_step, h->stream));
         }
         // the candidate's rotation tables (needed only if the step is accepted) are made while the host decides
-        h->rt_valid[nxt] = false;
-        st = launch_pose_prepare(h, nxt);
-        if (st) return st;
+        if (spec) {
+            hipLaunchKernelGGL(k_pose_prepare_cand, dim3((h->V + 127) / 128), dim3(128), 0, h->stream, h->d_poses[0], h->d_rt[0], h->V,
+                               h->poses_step, h->rt_step, h->d_lm);
+            CVX_HIP(hipGetLastError());
+        } else {
+            h->rt_valid[nxt] = false;
+            st = launch_pose_prepare(h, nxt);
+            if (st) return st;
+        }
+        return CVX_OK;
+    }
+    bool polled = false;
+
+    // wait for the 16 doubles of the step numbered seq (host record `slot`)
+    int wait_step(long long seq, int slot) {
+        rec = h->h_E2 + 32 * slot;
         if (polled) {
-            volatile const double *flag = h->h_E2 + 16;
+            volatile const double *flag = rec + 16;
+            const double want = (double)seq;
             const auto t0 = std::chrono::steady_clock::now();
             long long spins = 0;
-            while (*flag != seq) {
+            while (*flag != want) {
                 if ((++spins & 0xffff) == 0 &&
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
                     CVX_HIP(hipStreamSynchronize(h->stream));       // surfaces a kernel fault as a HIP error
-                    if (*flag != seq) { cvx::set_last_error("step result never arrived in host memory"); return CVX_ERR_HIP; }
+                    if (*flag != want) { cvx::set_last_error("step result never arrived in host memory"); return CVX_ERR_HIP; }
                 }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
@@ -806,6 +880,56 @@ private:
         ph_collect(h);
         if (h->nranks > 1 && h->xfn && !h->xdev) {
             if (h->xfn(h->xctx, h->h_E2, 4, 0, nullptr)) return CVX_ERR_EXCHANGE;
+        }
+        return CVX_OK;
+    }
+
+    // One linear step.  When the loop allows it (can_speculate) the step AFTER this one is enqueued before this one's
+    // result is awaited: its kernels take the point and the damping from the device-side record, which this step's last
+    // kernel moves on with the loop's own decision code.  The host then repeats that decision from the 16 doubles and
+    // finds, next time round, its step already under way -- or, where the record said "off", enqueues it as ever.
+    int run_step(const cvx_damping &d) {
+        const bool spec = can_speculate();
+        long long seq;
+        int st;
+        if (spec_inflight && spec_runs && spec) {
+            // this step is the one enqueued behind the last: its damping was the device's to work out -- the same number
+            seq = spec_seq;
+            ++h->n_spec_used;
+            const double *prev = h->h_E2 + 32 * ((seq - 1) & 1);
+            if (prev[17] != d.inv_radius || (int)prev[18] != h->cur) {
+                cvx::set_last_error("speculated step: the device-side trust-region state differs from the host's");
+                return CVX_ERR_NUMERIC;
+            }
+        } else {
+            if (spec_inflight) ++h->n_spec_dropped;
+            seq = ++h->step_seq;
+            if (spec) {
+                // a chain of speculated steps starts here: the record is the host's state before this step's decision
+                LmDev &r = *h->h_lm;
+                r.inv_radius = d.inv_radius; r.mu = d.mu; r.min_diag = d.min_diag; r.max_diag = d.max_diag;
+                r.cur = h->cur; r.active = 1; r.last_cand = -1; r.pad = 0;
+                r.min_lm_diagonal = d.min_diag; r.max_lm_diagonal = d.max_diag;
+                r.tr = snap_tr; r.opt = snap_opt;
+                st = launch_pose_prepare(h, h->cur);
+                if (st) return st;
+                CVX_HIP(hipMemcpyAsync(h->d_lm, h->h_lm, sizeof(LmDev), hipMemcpyHostToDevice, h->stream));
+            }
+            st = enqueue_step(d, spec, seq);
+            if (st) return st;
+        }
+        spec_inflight = false;
+        if (spec && snap_tr.it + 1 < snap_opt.max_iterations) {
+            spec_seq = ++h->step_seq;
+            st = enqueue_step(d, true, spec_seq);      // (d is not read: the record's damping is)
+            if (st) return st;
+            spec_inflight = true;
+        }
+        st = wait_step(seq, spec ? (int)(seq & 1) : 0);
+        if (st) return st;
+        if (spec) {
+            h->rt_valid[1 - h->cur] = true;             // k_pose_prepare_cand made the candidate's tables
+            spec_runs = rec[15] != 0.0;
         }
         return CVX_OK;
     }
@@ -979,16 +1103,23 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     }
     CVX_TRY(dev_upload(&h->d_glist, glist.data(), glist.size(), s));
     CVX_TRY(dev_upload(&h->d_glist_off, glist_off.data(), glist_off.size(), s));
-    for (int k = 0; k < 2; ++k) {
-        CVX_TRY(dev_alloc(&h->d_intr[k], 9 * (size_t)C));
-        CVX_TRY(dev_alloc(&h->d_points[k], 3 * (size_t)P));
-        CVX_TRY(dev_alloc(&h->d_poses[k], 6 * (size_t)V));
-        CVX_HIP(hipMemsetAsync(h->d_intr[k], 0, 9 * (size_t)C * sizeof(double), s));
-        CVX_HIP(hipMemsetAsync(h->d_points[k], 0, 3 * (size_t)P * sizeof(double), s));
-        if (V) CVX_HIP(hipMemsetAsync(h->d_poses[k], 0, 6 * (size_t)V * sizeof(double), s));
+    {
+        auto up32 = [](size_t n) { return (long long)((std::max<size_t>(n, 1) + 31) / 32 * 32); };
+        h->intr_step = up32(9 * (size_t)C); h->points_step = up32(3 * (size_t)P);
+        h->poses_step = up32(6 * (size_t)V); h->rt_step = up32((size_t)V * RT_STRIDE);
+        CVX_TRY(dev_alloc(&h->d_intr[0], 2 * (size_t)h->intr_step));
+        CVX_TRY(dev_alloc(&h->d_points[0], 2 * (size_t)h->points_step));
+        CVX_TRY(dev_alloc(&h->d_poses[0], 2 * (size_t)h->poses_step));
+        CVX_TRY(dev_alloc(&h->d_rt[0], 2 * (size_t)h->rt_step));
+        h->d_intr[1] = h->d_intr[0] + h->intr_step; h->d_points[1] = h->d_points[0] + h->points_step;
+        h->d_poses[1] = h->d_poses[0] + h->poses_step; h->d_rt[1] = h->d_rt[0] + h->rt_step;
+        CVX_HIP(hipMemsetAsync(h->d_intr[0], 0, 2 * (size_t)h->intr_step * sizeof(double), s));
+        CVX_HIP(hipMemsetAsync(h->d_points[0], 0, 2 * (size_t)h->points_step * sizeof(double), s));
+        CVX_HIP(hipMemsetAsync(h->d_poses[0], 0, 2 * (size_t)h->poses_step * sizeof(double), s));
+        CVX_TRY(dev_alloc(&h->d_lm, 1));
+        CVX_HIP(hipMemsetAsync(h->d_lm, 0, sizeof(LmDev), s));
+        CVX_HIP(hipHostMalloc((void **)&h->h_lm, sizeof(LmDev), hipHostMallocDefault));
     }
-    CVX_TRY(dev_alloc(&h->d_rt[0], (size_t)V * RT_STRIDE));
-    CVX_TRY(dev_alloc(&h->d_rt[1], (size_t)V * RT_STRIDE));
     const size_t zn = ((size_t)6 * V + 8) * h->ZC;
     CVX_TRY(dev_alloc(&h->d_Z, zn));
     CVX_HIP(hipMemsetAsync(h->d_Z, 0, zn * sizeof(double), s));
@@ -1017,8 +1148,9 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_HIP(hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
     CVX_TRY(dev_alloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
-    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 32 * sizeof(double), hipHostMallocMapped));
-    std::memset(h->h_E2, 0, 32 * sizeof(double));
+    // two records of 32 doubles (a speculated step may publish while the host still reads the one before)
+    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 64 * sizeof(double), hipHostMallocMapped));
+    std::memset(h->h_E2, 0, 64 * sizeof(double));
     if (hipHostGetDevicePointer((void **)&h->d_E2_map, h->h_E2, 0) != hipSuccess) h->d_E2_map = nullptr;
     // damped reduced solve: (ns + 1) rows (the right-hand side rides as row ns), padded to 32-tiles
     h->nT = (h->ns + 1 + cvxs::TB - 1) / cvxs::TB;
@@ -1237,6 +1369,12 @@ extern "C" int cvx_calib_phase_times(cvx_calib *h, double ms[16]) {
 
 // geometry the bench needs to state algorithmic work: [0] ZC, [1] ns, [2] n_groups, [3] n_chunks,
 // [4] upper-triangular tile pairs, [5] K2 threads per block, [6] Z rows
+extern "C" int cvx_calib_speculation_counts(const cvx_calib *h, int64_t out[2]) {
+    if (!h || !out) return CVX_ERR_INVALID_ARG;
+    out[0] = h->n_spec_used; out[1] = h->n_spec_dropped;
+    return CVX_OK;
+}
+
 extern "C" int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]) {
     if (!h || !out) return CVX_ERR_INVALID_ARG;
     out[0] = h->ZC; out[1] = h->ns; out[2] = h->n_groups; out[3] = h->n_chunks; out[4] = h->nblk;

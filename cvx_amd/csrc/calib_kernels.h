@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <vector>
 
+#include "trust_region.h"
+
 namespace cvxk {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -103,6 +105,57 @@ typedef const __attribute__((address_space(4))) double *uniform_f64;
 typedef const __attribute__((address_space(4))) int *uniform_i32;
 __device__ __forceinline__ uniform_f64 as_uniform(const double *p) { return (uniform_f64)p; }
 __device__ __forceinline__ uniform_i32 as_uniform(const int *p) { return (uniform_i32)p; }
+
+// -----------------------------------------------------------------------------------------
+// Speculated steps.  The trust-region loop's decision on a step (accept / reject, next radius, stopping tests) is
+// scalar arithmetic on 16 doubles; waiting for the host to make it leaves the GPU idle for a launch round trip per LM
+// iteration (10-15 us of a 400 us step at config 4).  So the step's last kernel makes the decision too (the same
+// code as the host's: trust_region.h), in a state record in device memory, and the kernels of the NEXT step -- already
+// enqueued -- take the point to linearise at and the damping from that record.  The host remains the authority: it
+// repeats every decision from the step's 16 doubles, and whenever the loop leaves its common path (a stopping test,
+// an uphill step that wants the best point saved, inner iterations, the iteration limit) the record says "inactive"
+// and the kernels already enqueued return at once.
+// -----------------------------------------------------------------------------------------
+struct LmDev {
+    double inv_radius, mu, min_diag, max_diag;   // damping of the step in flight
+    int cur;                                     // which of the two parameter buffers holds the current point
+    int active;                                  // 1: the kernels that read this record run; 0: they return at once
+    int last_cand, pad;                          // buffer of the candidate the last step made (-1: it did not run)
+    double min_lm_diagonal, max_lm_diagonal;
+    cvx::TrState tr;                             // the loop's state BEFORE the decision on the step in flight
+    cvx::TrOptions opt;
+};
+typedef const __attribute__((address_space(4))) LmDev *uniform_lm;
+__device__ __forceinline__ uniform_lm as_uniform(const LmDev *p) { return (uniform_lm)p; }
+
+// The 16 doubles R a linear step leaves (k_backsubst_cost_step / k_step_finish / k_final_scalars) as the loop reads them
+__host__ __device__ inline cvx::TrStep step_from_record(const double *R, double gtol, double *cost) {
+    cvx::TrStep s;
+    s.grad_converged = 0; s.ok = 0; s.cand_cost = 0.0; s.model_change = 0.0; s.step_norm2 = 0.0; s.x_norm2 = 0.0;
+    *cost = 0.5 * R[11];
+    s.grad_max = R[9] > R[13] ? R[9] : R[13];
+    if (s.grad_max <= gtol) { s.grad_converged = 1; return s; }
+    if (R[12] > 0 || R[8] > 0) return s;
+    s.cand_cost = 0.5 * R[0];
+    s.model_change = 0.5 * (R[1] + R[4]);
+    s.step_norm2 = R[2] + R[5];
+    s.x_norm2 = R[3] + R[6];
+    // finite: |x| < inf (false for NaN), the same test on host and device
+    s.ok = (fabs(s.model_change) < INFINITY) && (fabs(s.step_norm2) < INFINITY);
+    return s;
+}
+
+// Rotation tables of the candidate a speculated step has just made (poses / rt: buffer 0's).  It runs BEHIND the
+// step's decision, which may have renamed the buffers, so the decision leaves the candidate's buffer in `last_cand`
+// (-1: the step did not run).
+__global__ void k_pose_prepare_cand(const double *__restrict__ poses, double *__restrict__ rt, int V, long long poses_step,
+                                    long long rt_step, const LmDev *__restrict__ st) {
+    const int which = as_uniform(st)->last_cand;
+    if (which < 0) return;
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    pose_table(poses + which * poses_step + 6 * (size_t)v, rt + which * rt_step + (size_t)v * RT_STRIDE);
+}
 
 // residual only (calibration.cpp:266-311)
 template <class RT>
@@ -367,6 +420,10 @@ struct K2Args {
     int P, ZC, camcol0, ycol, cam_free, pts_free;
     double inv_radius, mu, min_diag, max_diag;
     double *Z, *Lfac, *Dv, *gv, *s2pose_out, *slab_pt, *slab_cam, *grp_scal;
+    // speculated steps (st != null): intr / points / rt are buffer 0's, buffer 1 lies `*_step` doubles behind; the
+    // current buffer and the damping come from the record
+    const LmDev *st;
+    long long intr_step, points_step, rt_step;
 };
 
 #ifndef K2_MIN_WAVES
@@ -377,6 +434,13 @@ __global__ void __launch_bounds__(T, K2_MIN_WAVES) k_normal_eq(K2Args a) {
     extern __shared__ double lds[];
     constexpr int W = T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.st) {
+        const uniform_lm st = as_uniform(a.st);
+        if (!st->active) return;
+        const long long cur = st->cur;
+        a.intr += cur * a.intr_step; a.points += cur * a.points_step; a.rt += cur * a.rt_step;
+        a.inv_radius = st->inv_radius; a.mu = st->mu; a.min_diag = st->min_diag; a.max_diag = st->max_diag;
+    }
 #ifdef K2_WALL
     const long long w_start = wall_clock64();
     long long w_pro = 0, w_loop = 0;
@@ -1267,6 +1331,7 @@ struct AsmArgs {
     // scalars] -- half of E; X == nullptr otherwise
     double *X;
     int n_scal;
+    const LmDev *st;      // speculated steps: the damping comes from the record
 };
 
 struct SharedIdx {
@@ -1310,6 +1375,11 @@ __device__ __forceinline__ double tile_sum(const AsmArgs &a, int cam, int zi, in
 // Thread grid: pitch x pitch matrix entries, then ns vector entries; pitch = ns, or npad when A is written too
 // (the entries outside ns x ns are then A's right-hand-side row, its 1e300 pivot and the identity padding).
 __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
+    if (a.st) {
+        const uniform_lm st = as_uniform(a.st);
+        if (!st->active) return;
+        a.inv_radius = st->inv_radius; a.mu = st->mu; a.min_diag = st->min_diag; a.max_diag = st->max_diag;
+    }
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nn = (long long)a.ns * a.ns;
     const int pitch = a.A ? a.npad : a.ns;
@@ -1450,6 +1520,93 @@ __global__ void __launch_bounds__(64) k_publish_scalars(const double *__restrict
     __threadfence_system();
     __builtin_amdgcn_wave_barrier();
     if (threadIdx.x == 0) {
+        host_copy[16] = seq;
+        __threadfence_system();
+    }
+}
+
+// k_final_scalars of a speculated step, with the loop's decision behind the sums (trust_region.h: the host runs the same
+// functions on the same 16 doubles).  The record moves on to the NEXT step: current buffer, damping, state; `active`
+// stays 1 only on the loop's common path -- the step accepted (and no best point to save) or rejected or invalid, the
+// solve not stopped, iterations left.  The 16 doubles go to the host as k_final_scalars sends them, R[15] = 1 when the
+// kernels enqueued behind this one will run.
+__global__ void __launch_bounds__(1024) k_final_scalars_decide(const double *__restrict__ cost_partial, int n_partial,
+                                                               const double *__restrict__ out_view, int V,
+                                                               double *__restrict__ E2, double *__restrict__ host_copy,
+                                                               double seq, LmDev *__restrict__ st) {
+    if (!as_uniform(st)->active) {
+        if (threadIdx.x == 0) st->last_cand = -1;
+        return;
+    }
+    __shared__ double sh[4][16];
+    __shared__ double rec[20];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nmax = n_partial > V ? n_partial : V;
+    for (int base = 0; base < nmax; base += 8 * 1024) {
+        double v[4][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + (int)threadIdx.x + u * 1024;
+            v[0][u] = i < n_partial ? cost_partial[i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k + 1][u] = i < V ? out_view[(size_t)k * V + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            s[k] += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
+        if (lane == 0) sh[k][wave] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double v;
+        if (threadIdx.x < 4) {
+            const double *q = sh[threadIdx.x];
+            v = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+                (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+            E2[threadIdx.x] = v;
+        } else {
+            v = E2[threadIdx.x];
+        }
+        rec[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cvx::TrState tr = st->tr;
+        const cvx::TrOptions opt = st->opt;
+        const int cand_buf = 1 - st->cur;
+        double cost_now;
+        const cvx::TrStep step = step_from_record(rec, tr.need_gcheck ? opt.gradient_tolerance : -1.0, &cost_now);
+        cvx::TrTrace trace;
+        int what = cvx::tr_begin_step(tr, step, trace), save_best = 0;
+        if (what == cvx::TR_GO_ON)
+            what = cvx::tr_finish_step(tr, opt, step.cand_cost, step.model_change, step.step_norm2, step.x_norm2, 0, trace, &save_best);
+        const bool moves = what == cvx::TR_ACCEPTED && !save_best;
+        const bool go_on = (moves || what == cvx::TR_REJECTED || what == cvx::TR_INVALID) && !tr.term && tr.it < opt.max_iterations;
+        st->tr = tr;
+        if (moves) st->cur = cand_buf;
+        st->last_cand = cand_buf;
+        st->inv_radius = 1.0 / tr.radius; st->mu = 0.0; st->min_diag = st->min_lm_diagonal; st->max_diag = st->max_lm_diagonal;
+        st->active = go_on ? 1 : 0;
+        rec[15] = go_on ? 1.0 : 0.0;
+        E2[15] = rec[15];
+        rec[16] = 0.0; rec[17] = st->inv_radius; rec[18] = (double)st->cur;     // what the next step will run with
+    }
+    __syncthreads();
+    if (threadIdx.x < 19 && threadIdx.x != 16) {
+        const double v = rec[threadIdx.x];
+        if (host_copy) {
+            host_copy[threadIdx.x] = v;
+            __threadfence_system();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (host_copy && threadIdx.x == 0) {
         host_copy[16] = seq;
         __threadfence_system();
     }

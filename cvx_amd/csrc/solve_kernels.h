@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+namespace cvxk { struct LmDev; }
+
 namespace cvxs {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -303,6 +305,10 @@ struct FinishArgs {
     int C, P, ncf, fix_k3, cam_free, pts_free, ZC, camcol0, ycol;
     const double *intr, *points;
     double *intr_cand, *points_cand, *ds_emb, *delta_s, *R;
+    // speculated steps (calib_kernels.h): the four parameter pointers are buffer 0's, buffer 1 lies `*_step` doubles
+    // behind, and the record says which one is current
+    const cvxk::LmDev *st;
+    long long intr_step, points_step, poses_step;
 };
 
 // block reductions of the finish kernel: wave butterflies, then four partials through LDS

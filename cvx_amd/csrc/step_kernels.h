@@ -41,6 +41,15 @@ __global__ void __launch_bounds__(BSC_THREADS) k_backsubst_cost_step(const doubl
                                                                      const double *__restrict__ obs_y,
                                                                      double *__restrict__ cost_view, cvxs::FinishArgs f) {
     extern __shared__ double sm[];
+    if (f.st) {
+        // a speculated step: which buffer is current is the record's to say (uniform loads: the whole grid agrees)
+        const uniform_lm st = as_uniform(f.st);
+        if (!st->active) return;
+        const long long cur = st->cur, nxt = 1 - cur;
+        f.intr_cand = const_cast<double *>(f.intr) + nxt * f.intr_step; f.intr += cur * f.intr_step;
+        f.points_cand = const_cast<double *>(f.points) + nxt * f.points_step; f.points += cur * f.points_step;
+        poses_cand = const_cast<double *>(poses) + nxt * f.poses_step; poses += cur * f.poses_step;
+    }
     const double *__restrict__ x = f.delta_s;      // the solution of the reduced system (last k_chol_step launch)
     if (blockIdx.x == 0) {
         // k_step_finish's part, before any wave of the workgroup can leave

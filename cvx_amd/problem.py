@@ -109,6 +109,12 @@ class Calib:
         check(lib().cvx_calib_time_schur(self.h, int(reps), C.byref(ms)), "cvx_calib_time_schur")
         return ms.value
 
+    def speculation_counts(self):
+        """(speculated steps the loop used, speculated steps it switched off) since the handle was made"""
+        g = (C.c_int64 * 2)()
+        check(lib().cvx_calib_speculation_counts(self.h, g), "speculation counts")
+        return int(g[0]), int(g[1])
+
     def geometry(self):
         g = (C.c_int64 * 8)()
         check(lib().cvx_calib_geometry(self.h, g), "geometry")

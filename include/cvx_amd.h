@@ -227,6 +227,14 @@ int cvx_calib_time_schur(cvx_calib *h, int reps, double *ms_per_launch);
  * [5] threads per normal-equation workgroup, [6] Z rows (6 * n_views), [7] 32-column tile columns of the reduced
  * solve (launches of k_chol_step per LM iteration) */
 int cvx_calib_geometry(const cvx_calib *h, int64_t out[8]);
+/* Speculated steps since the handle was made.  With CVX_CALIB_SPECULATE=1 in the environment cvx_calib_solve (strategy
+ * 0, one rank, once the inner iterations have switched themselves off) enqueues the next LM step before the host has
+ * seen the current one's result: the step's last kernel takes the loop's decision on the device with the host's own
+ * code (trust_region.h), and the host repeats it -- results are the same bit for bit.  Off by default: on MI355X it is
+ * 1 % slower than waiting for the host.
+ * out[0]: steps that ran that way; out[1]: steps enqueued ahead that the loop switched off (a stopping test, an uphill
+ * step whose best point had to be saved, the iteration limit) -- their kernels return at once. */
+int cvx_calib_speculation_counts(const cvx_calib *h, int64_t out[2]);
 
 /* ------------------------------------------------------------------------ */
 /* Hand-eye AX = XB refinement (HandEyeCalibration::solveNonLinear)          */

@@ -304,3 +304,65 @@ def test_full_size_config4_properties(orc):
     s2 = g.solve(capi.options("refine"))
     assert s2.iterations <= 2 and abs(s2.final_cost - s.final_cost) <= 1e-9 * s.final_cost
     g.close()
+
+
+@pytest.mark.parametrize("case", ["config1", "two_cameras_ragged", "three_cameras_free_k3_big_board", "fixed_intrinsics",
+                                  "five_column_groups"])
+@pytest.mark.parametrize("inner", [0, 1])
+def test_speculated_steps_equal_the_host_driven_loop_bit_for_bit(orc, monkeypatch, case, inner):
+    """With CVX_CALIB_SPECULATE=1 cvx_calib_solve enqueues the NEXT LM step before the host has seen this one's result:
+    the step's last kernel takes the trust-region loop's decision on the device (trust_region.h, the host's own code)
+    and the kernels behind it read the point and the damping from a device-side record.  The host repeats every
+    decision, so a solve must come out the same as the default (every decision waits for the host) bit for bit: trace, summary,
+    parameters -- with and without inner iterations (the passes are host-driven: speculation starts once they have
+    switched themselves off), non-monotonic steps included (refine's options), and again on a second solve of the same
+    handle (stale records)."""
+    d, g, o = make(case, orc)
+    x = (d["intr_init"], d["poses_init"], d["points_init"])
+    opt = capi.options("refine")
+    opt.inner_iterations = inner
+    runs = []
+    for host_loop in ("0", "1", "0"):
+        monkeypatch.setenv("CVX_CALIB_SPECULATE", "0" if host_loop == "1" else "1")
+        g.set_params(*x)
+        used0 = g.speculation_counts()[0]
+        s = g.solve(opt)
+        # the speculated path really ran (all but the first step of a chain), and not when told to wait for the host
+        used = g.speculation_counts()[0] - used0
+        assert used == 0 if host_loop == "1" else used >= s.iterations - s.num_inner_iteration_steps - 3
+        runs.append((s.iterations, s.termination, s.num_successful, s.num_linear_solves, s.final_cost,
+                     {k: v.copy() for k, v in s.trace().items()}, [p.copy() for p in g.get_params()]))
+    monkeypatch.delenv("CVX_CALIB_SPECULATE")
+    ref = runs[1]
+    assert ref[0] >= 5
+    for r in (runs[0], runs[2]):
+        assert r[:5] == ref[:5]
+        for k in ("cost", "accepted", "damping", "gradient"):
+            assert np.array_equal(r[5][k], ref[5][k], equal_nan=True), k
+        for a, b in zip(r[6], ref[6]):
+            assert np.array_equal(a, b)
+    g.close()
+
+
+def test_speculated_steps_stop_at_the_iteration_limit_and_at_tolerances(orc, monkeypatch):
+    """max_iterations cuts a speculated chain (no step beyond the limit may touch the parameters), and a chain that ends
+    on a tolerance leaves the accepted point in place: the parameters read back equal the host-driven run's, and a
+    second solve from there starts at the cost the first one reported."""
+    d, g, o = make("two_cameras_ragged", orc)
+    x = (d["intr_init"], d["poses_init"], d["points_init"])
+    for k in (1, 2, 3, 7):
+        opt = capi.options("refine")
+        opt.inner_iterations = 0
+        opt.max_iterations = k
+        out = []
+        for host_loop in ("0", "1"):
+            monkeypatch.setenv("CVX_CALIB_SPECULATE", "0" if host_loop == "1" else "1")
+            g.set_params(*x)
+            s = g.solve(opt)
+            out.append((s.iterations, s.termination, s.final_cost, [p.copy() for p in g.get_params()], g.cost()))
+        assert out[0][:3] == out[1][:3] and out[0][0] == k
+        for a, b in zip(out[0][3], out[1][3]):
+            assert np.array_equal(a, b)
+        assert out[0][4] == out[1][4] and abs(out[0][4] - out[0][2]) <= 1e-12 * out[0][2]
+    monkeypatch.delenv("CVX_CALIB_SPECULATE")
+    g.close()
