@@ -30,8 +30,10 @@ __device__ __forceinline__ double step_emb(const cvxs::FinishArgs &a, const doub
 }
 
 constexpr int BSC_THREADS = 256;
+// (five waves per SIMD: 96 registers, one spilled -- 40.1 us against 41.7 at the four the compiler picks on its own; six
+//  waves spill 21 registers, 50.5 us; the view's first observations loaded ahead of the pass over Z: 42.4-44.2 us)
 
-__global__ void __launch_bounds__(BSC_THREADS) k_backsubst_cost_step(const double *__restrict__ Z, const double *__restrict__ Lfac,
+__global__ void __launch_bounds__(BSC_THREADS, 5) k_backsubst_cost_step(const double *__restrict__ Z, const double *__restrict__ Lfac,
                                                                      const double *__restrict__ Dv, const double *__restrict__ gv,
                                                                      const int *__restrict__ cam_of_view,
                                                                      const double *__restrict__ poses, double *__restrict__ poses_cand,

@@ -1,7 +1,7 @@
 """One inner-iteration pass (cvx_calib_inner_pass) at BASELINE config 4 from the perturbed start, repeated: wall time
 per pass; run under rocprofv3 --kernel-trace --stats for the per-kernel split (profiles/r02f_inner_*)."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cvx_amd
 d = cvx_amd.synth_calib(8, 1250, 12, 9, 20260004)
 g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 8, 108)
