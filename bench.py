@@ -305,6 +305,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 1 / 3 / 5 block (profiling runs: keeps every kernel's launches at config 4's size)")
     ap.add_argument("--cpu-views", type=int, default=1250, help="views per camera of the CPU sample")
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--host-exchange", action="store_true", help="all-reduce host copies instead of device buffers")
@@ -482,14 +483,14 @@ def main():
 
     # ---- the other calibration configurations of BASELINE.json, the same step (ms per LM iteration) ----
     configs = config5_strong = None
-    if world == 1:
+    if world == 1 and not a.no_configs:
         configs = {}
         for name, spec in (("config1", (1, 20, 9, 6, 20260001)), ("config3", (2, 500, 12, 9, 20260003)),
                            ("config5", (8, 12500, 12, 9, 20260005))):
             r = lm_iteration_ms(cvx_amd, capi, torch, spec, local_rank, steps=20)
             r["observation_iterations_per_s"] = r["observations"] * r["steps"] / r["seconds"]
             configs[name] = r
-    else:
+    elif world > 1:
         # north_star's config 5 ("100k views x 108 corners, 8xMI355X"): ONE 10.8 M-observation problem cut by view over
         # the ranks -- the configuration where the per-rank kernels dominate the replicated reduced solve
         trace("config 5, strong")

@@ -4,7 +4,7 @@
 tag=${1:-x}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_${tag}_fp64 -o fp64 -- python3 $root/bench.py --steps 10 --warmup 10 --no-cpu-baseline > $root/gpurun_out/pmc_${tag}_fp64.json 2> $root/gpurun_out/pmc_${tag}_fp64.err || { tail -5 $root/gpurun_out/pmc_${tag}_fp64.err; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $root/gpurun_out/pmc_${tag}_fp64 -o fp64 -- python3 $root/bench.py --steps 10 --warmup 10 --no-cpu-baseline --no-configs > $root/gpurun_out/pmc_${tag}_fp64.json 2> $root/gpurun_out/pmc_${tag}_fp64.err || { tail -5 $root/gpurun_out/pmc_${tag}_fp64.err; exit 1; }
 cd $root && python3 - <<PY
 import csv, glob, collections
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()

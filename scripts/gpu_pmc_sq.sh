@@ -4,7 +4,7 @@
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $root/gpurun_out/sq_$tag -o sq -- python3 $root/bench.py --steps 10 --warmup 5 --no-cpu-baseline > $root/gpurun_out/sq_$tag.json 2> $root/gpurun_out/sq_$tag.err || { tail -5 $root/gpurun_out/sq_$tag.err; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $root/gpurun_out/sq_$tag -o sq -- python3 $root/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-configs > $root/gpurun_out/sq_$tag.json 2> $root/gpurun_out/sq_$tag.err || { tail -5 $root/gpurun_out/sq_$tag.err; exit 1; }
 cd $root && python3 - <<PY
 import csv, collections, glob
 f = glob.glob("gpurun_out/sq_$tag/**/*counter_collection.csv", recursive=True)[0]
