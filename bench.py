@@ -528,6 +528,16 @@ def main():
             torch.cuda.synchronize()
             handeye[name] = {"pairs": int(len(A)), "ms_per_lm_iteration": 1e3 * (time.perf_counter() - th) / (reps * max(hs.iterations, 1)),
                              "iterations_per_solve": hs.iterations, "final_cost": hs.final_cost}
+            # and the solve as solveNonLinear itself runs it (handeye.cpp:310-319: Ceres' default tolerances)
+            hd = capi.options("handeye")
+            he.solve(x0, hd)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(reps):
+                p, hs = he.solve(x0, hd)
+            handeye[name]["solve_with_the_reference_options"] = {"ms_per_solve": 1e3 * (time.perf_counter() - th) / reps,
+                                                                 "iterations": hs.iterations, "accepted": hs.num_successful,
+                                                                 "termination": hs.termination}
             he.close()
             if world == 1 and not a.no_cpu_baseline:
                 handeye[name]["cpu_baseline"] = handeye_cpu_baseline(q, x0, 20 if moving else 5)

@@ -170,6 +170,9 @@ public:
     double x[7], xc[7];
     double H[36], g[6], cost = 0;
     double s2[6] = {1, 1, 1, 1, 1, 1};
+    double Hc[36], gc[6], cand_cost_kept = 0;     // the candidate's linearisation (try_step), taken over by accept()
+    bool cand_lin = false;
+    bool likely_accept = true;                    // the last step was accepted (or none was taken yet)
     bool lin_valid = false, projected = true;
 
     void set_strategy(int strategy) override { projected = (strategy == 0); }
@@ -212,6 +215,7 @@ public:
 
     cvx::StepInfo try_step(const cvx_damping &d, double gtol, bool gradient_only) override {
         cvx::StepInfo out;
+        cand_lin = false;
         out.status = linearize();
         if (out.status) return out;
         out.cost = cost; out.grad_max = grad_norm();
@@ -230,13 +234,23 @@ public:
         for (int a = 0; a < 6 && solved; ++a) solved = std::isfinite(delta[a]);
         if (!solved) { out.ok = false; return out; }
         plus7(x, delta, xc);
+        // After an accepted step (and at the start) the candidate is evaluated with the NORMAL-EQUATION kernel, not the cost
+        // kernel: its 28th sum is the cost, and if this step is accepted too -- the usual case while the solve still
+        // moves -- the other 27 are the next iteration's linearisation, which then costs no launch and no round trip to
+        // the host (solveNonLinear's own options, 3 iterations: 1 738 pairs 154 -> 121 us per solve, 19 548 pairs
+        // 214 -> 185).  After a rejected step the cost kernel is used (the normal-equation kernel is 8 us longer).
         double cand = 0;
-        out.status = device_cost(h, xc, &cand);
+        const bool with_lin = likely_accept;
+        likely_accept = false;
+        if (with_lin) out.status = device_normal_eq(h, xc, Hc, gc, &cand);
+        else out.status = device_cost(h, xc, &cand);
         if (out.status) return out;
+        cand_lin = with_lin;
         double m = 0, sn = 0, xn = 0;
         for (int a = 0; a < 6; ++a) m += delta[a] * (D[a] * delta[a] - g[a]);
         for (int i = 0; i < 7; ++i) { sn += (x[i] - xc[i]) * (x[i] - xc[i]); xn += x[i] * x[i]; }
         out.cand_cost = cand; out.model_change = 0.5 * m;
+        cand_cost_kept = cand;
         // levmar's ||Dp||^2 is over the 6 tangent coordinates, Ceres' step norm over the 7 global ones
         double d2 = 0;
         for (int a = 0; a < 6; ++a) d2 += delta[a] * delta[a];
@@ -248,7 +262,13 @@ public:
 
     int accept() override {
         std::memcpy(x, xc, sizeof x);
-        lin_valid = false;
+        likely_accept = true;
+        lin_valid = cand_lin;
+        if (cand_lin) {
+            std::memcpy(H, Hc, sizeof H); std::memcpy(g, gc, sizeof g);
+            cost = cand_cost_kept;
+        }
+        cand_lin = false;
         return CVX_OK;
     }
     double xbest[7];

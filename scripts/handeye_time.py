@@ -22,4 +22,11 @@ for moving, n in ((True, 200), (False, 60), (False, 90), (False, 200)):
             p, hs = he.solve(x0, ho)
         dt = (time.perf_counter() - t) / 20
         print("pairs %6d  %2d iterations: %.1f us per solve, %.2f us per LM iteration" % (len(A), hs.iterations, 1e6 * dt, 1e6 * dt / hs.iterations))
+    ho = capi.options("handeye")        # the reference's own options: the solve as solveNonLinear runs it
+    he.solve(x0, ho)
+    t = time.perf_counter()
+    for _ in range(20):
+        p, hs = he.solve(x0, ho)
+    dt = (time.perf_counter() - t) / 20
+    print("pairs %6d  default options: %d iterations (%d accepted), %.1f us per solve" % (len(A), hs.iterations, hs.num_successful, 1e6 * dt))
     he.close()
