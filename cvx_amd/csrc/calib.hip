@@ -42,6 +42,16 @@ __global__ void k_fill(double *p, long long n, double v) {
     if (i < n) p[i] = v;
 }
 
+// Jacobi scales of the shared unknowns, s_j^2 = 1 / (1 + sqrt(d_j))^2 (or 1), from the diagonal the assembly left in E:
+// made on the device so that a solve's set-up uploads nothing
+__global__ void k_shared_scales(const double *__restrict__ dU, double *__restrict__ s2, int n, int jacobi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = 1.0;
+    if (jacobi) { const double s = 1.0 / (1.0 + sqrt(dU[i])); v = s * s; }
+    s2[i] = v;
+}
+
 enum { PH_NORMAL = 0, PH_SCHUR, PH_ASSEMBLE, PH_BACKSUBST, PH_COST, PH_SOLVE, PH_COUNT };
 
 }  // namespace
@@ -81,6 +91,7 @@ struct cvx_calib {
     double *d_slab_pt = nullptr, *d_slab_cam = nullptr, *d_grp_scal = nullptr, *d_slab_tile = nullptr;
     double *d_Tpt = nullptr, *d_Tt = nullptr, *d_Gcam = nullptr;
     double *d_E = nullptr, *h_E = nullptr;
+    double *h_params = nullptr;      // pinned: 9 C + 3 P + 6 V doubles, set_params / get_params stage through it
     double *d_X = nullptr;           // ranks > 1: the exchanged buffer (packed lower triangle of S + the tail of E); h_E stages it
     size_t X_count = 0, X_tail = 0;
     size_t E_count = 0, E_scal = 0;
@@ -96,7 +107,7 @@ struct cvx_calib {
     double *d_A = nullptr, *d_s2sh = nullptr, *d_Ds = nullptr, *d_delta_s = nullptr;
     int *d_fail = nullptr;
     size_t fin_lds = 0;
-    std::vector<double> s2_shared, h_tail, h_A;
+    std::vector<double> h_A;
     // inner iterations (inner_kernels.h), made on first use
     bool inner_ready = false;
     int inner_sets = 0;
@@ -135,6 +146,7 @@ cvx_calib::~cvx_calib() {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h_E) (void)hipHostFree(h_E);
+    if (h_params) (void)hipHostFree(h_params);
     if (h_ds_emb) (void)hipHostFree(h_ds_emb);
     if (h_E2) (void)hipHostFree(h_E2);
     if (h_lm) (void)hipHostFree(h_lm);
@@ -610,24 +622,20 @@ public:
         cvx_damping d0 = {0, 0, 0, 0};
         out.status = linearize(h, d0, true, jacobi);
         if (out.status) return out;
-        // the tail of E: gred | gs | diagU | scalars
+        // the tail of E: gred | gs | diagU | scalars -- into pinned memory (h_E is free between two exchanges); the
+        // shared unknowns' scales are made from it on the device
         const size_t nn = (size_t)h->ns * h->ns, tail = h->E_count - nn;
-        h->h_tail.resize(tail);
-        if (hipMemcpyAsync(h->h_tail.data(), h->d_E + nn, tail * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        if (h->ns > 0) {
+            hipLaunchKernelGGL(k_shared_scales, dim3((h->ns + 255) / 256), dim3(256), 0, h->stream, h->d_E + nn + 2 * (size_t)h->ns,
+                               h->d_s2sh, h->ns, jacobi ? 1 : 0);
+        }
+        if (hipMemcpyAsync(h->h_E, h->d_E + nn, tail * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { out.status = CVX_ERR_HIP; return out; }
         ph_collect(h);
-        const double *gs = h->h_tail.data() + h->ns, *dU = gs + h->ns, *scal = h->h_tail.data() + 3 * (size_t)h->ns;
+        const double *gs = h->h_E + h->ns, *dU = gs + h->ns, *scal = h->h_E + 3 * (size_t)h->ns;
         double gm = 0, dm = 0;
         for (int q = 0; q < h->nranks; ++q) { gm = std::max(gm, scal[2 + q]); dm = std::max(dm, scal[2 + h->nranks + q]); }
-        for (int i = 0; i < h->ns; ++i) {
-            gm = std::max(gm, std::fabs(gs[i])); dm = std::max(dm, dU[i]);
-            if (jacobi) { const double s = 1.0 / (1.0 + std::sqrt(dU[i])); h->s2_shared[i] = s * s; }
-            else h->s2_shared[i] = 1.0;
-        }
-        if (h->ns > 0 &&
-            hipMemcpyAsync(h->d_s2sh, h->s2_shared.data(), sizeof(double) * h->ns, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
-            out.status = CVX_ERR_HIP; return out;
-        }
+        for (int i = 0; i < h->ns; ++i) { gm = std::max(gm, std::fabs(gs[i])); dm = std::max(dm, dU[i]); }
         out.cost = 0.5 * scal[0]; out.grad_max = gm; out.diag_max = dm;
         return out;
     }
@@ -641,11 +649,10 @@ public:
             out.status = linearize(h, d0, true, false);
             if (out.status) return out;
             const size_t nn = (size_t)h->ns * h->ns, tail = h->E_count - nn;
-            h->h_tail.resize(tail);
-            if (hipMemcpyAsync(h->h_tail.data(), h->d_E + nn, tail * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            if (hipMemcpyAsync(h->h_E, h->d_E + nn, tail * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
                 hipStreamSynchronize(h->stream) != hipSuccess) { out.status = CVX_ERR_HIP; return out; }
             ph_collect(h);
-            const double *gs = h->h_tail.data() + h->ns, *scal = h->h_tail.data() + 3 * (size_t)h->ns;
+            const double *gs = h->h_E + h->ns, *scal = h->h_E + 3 * (size_t)h->ns;
             double gm = 0;
             for (int q = 0; q < h->nranks; ++q) gm = std::max(gm, scal[2 + q]);
             for (int i = 0; i < h->ns; ++i) gm = std::max(gm, std::fabs(gs[i]));
@@ -1164,8 +1171,9 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(dev_alloc(&h->d_fail, 1));
     h->fin_lds = sizeof(double) * cvxs::finish_lds_doubles(h->ns);
 #undef CVX_TRY
-    h->s2_shared.assign((size_t)std::max(1, h->ns), 1.0);
-    CVX_HIP(hipMemcpyAsync(h->d_s2sh, h->s2_shared.data(), sizeof(double) * std::max(1, h->ns), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_fill, dim3((std::max(1, h->ns) + 255) / 256), dim3(256), 0, s, h->d_s2sh, (long long)std::max(1, h->ns), 1.0);
+    CVX_HIP(hipHostMalloc((void **)&h->h_params, sizeof(double) * std::max<size_t>(1, 9 * (size_t)h->C + 3 * (size_t)h->P + 6 * (size_t)h->V),
+                          hipHostMallocDefault));
     for (int i = 0; i < PH_COUNT; ++i) {
         CVX_HIP(hipEventCreate(&h->ev[i][0]));
         CVX_HIP(hipEventCreate(&h->ev[i][1]));
@@ -1183,9 +1191,16 @@ extern "C" int cvx_calib_set_params(cvx_calib *h, const double *intr, const doub
     CVX_HIP(hipSetDevice(h->device));
     const int c = h->cur;
     h->rt_valid[c] = false;
-    CVX_HIP(hipMemcpyAsync(h->d_intr[c], intr, sizeof(double) * 9 * h->C, hipMemcpyHostToDevice, h->stream));
-    CVX_HIP(hipMemcpyAsync(h->d_points[c], points, sizeof(double) * 3 * h->P, hipMemcpyHostToDevice, h->stream));
-    if (h->V) CVX_HIP(hipMemcpyAsync(h->d_poses[c], poses, sizeof(double) * 6 * (size_t)h->V, hipMemcpyHostToDevice, h->stream));
+    // through the handle's pinned staging block: three asynchronous copies and one wait (copies from pageable memory wait
+    // one by one)
+    double *sp = h->h_params;
+    const size_t ni = 9 * (size_t)h->C, np = 3 * (size_t)h->P, nv = 6 * (size_t)h->V;
+    std::memcpy(sp, intr, sizeof(double) * ni);
+    std::memcpy(sp + ni, points, sizeof(double) * np);
+    if (nv) std::memcpy(sp + ni + np, poses, sizeof(double) * nv);
+    CVX_HIP(hipMemcpyAsync(h->d_intr[c], sp, sizeof(double) * ni, hipMemcpyHostToDevice, h->stream));
+    CVX_HIP(hipMemcpyAsync(h->d_points[c], sp + ni, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+    if (nv) CVX_HIP(hipMemcpyAsync(h->d_poses[c], sp + ni + np, sizeof(double) * nv, hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
     return CVX_OK;
 }
@@ -1194,11 +1209,15 @@ extern "C" int cvx_calib_get_params(cvx_calib *h, double *intr, double *poses, d
     if (!h) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
     const int c = h->cur;
-    if (intr) CVX_HIP(hipMemcpyAsync(intr, h->d_intr[c], sizeof(double) * 9 * h->C, hipMemcpyDeviceToHost, h->stream));
-    if (points) CVX_HIP(hipMemcpyAsync(points, h->d_points[c], sizeof(double) * 3 * h->P, hipMemcpyDeviceToHost, h->stream));
-    if (poses && h->V)
-        CVX_HIP(hipMemcpyAsync(poses, h->d_poses[c], sizeof(double) * 6 * (size_t)h->V, hipMemcpyDeviceToHost, h->stream));
+    double *sp = h->h_params;
+    const size_t ni = 9 * (size_t)h->C, np = 3 * (size_t)h->P, nv = 6 * (size_t)h->V;
+    if (intr) CVX_HIP(hipMemcpyAsync(sp, h->d_intr[c], sizeof(double) * ni, hipMemcpyDeviceToHost, h->stream));
+    if (points) CVX_HIP(hipMemcpyAsync(sp + ni, h->d_points[c], sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    if (poses && nv) CVX_HIP(hipMemcpyAsync(sp + ni + np, h->d_poses[c], sizeof(double) * nv, hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
+    if (intr) std::memcpy(intr, sp, sizeof(double) * ni);
+    if (points) std::memcpy(points, sp + ni, sizeof(double) * np);
+    if (poses && nv) std::memcpy(poses, sp + ni + np, sizeof(double) * nv);
     return CVX_OK;
 }
 
