@@ -48,6 +48,12 @@ def test_two_rank_bench_line_strong_scaling():
     assert abs(c5["value"] - 10800000 * 20 / c5["seconds"]) <= 1e-6 * c5["value"]
     assert c5["cost"][1] < 1e-3 * c5["cost"][0]                 # the sharded iterations do converge
     assert "configs" not in d                                   # the one-GPU blocks stay out of the N > 1 line
+    # and the weak reading beside it: a config-4-sized shard per rank, one problem of twice the views
+    w = d["config4_weak"]
+    assert w["observations"] == 2 * 1080000 and w["pose_blocks"] == 20000 and w["views_this_rank"] == 10000
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["shared_unknowns"] == 388 and w["steps"] == 20
+    assert abs(w["value"] - 2 * 1080000 * 20 / w["seconds"]) <= 1e-6 * w["value"]
+    assert w["cost"][1] < 1e-3 * w["cost"][0]
 
 
 def test_two_rank_bench_line_weak_scaling():
@@ -55,3 +61,4 @@ def test_two_rank_bench_line_weak_scaling():
     assert d["config"]["observations_total"] == 2 * 1080000 and d["config"]["observations_rank0"] == 1080000
     assert abs(d["value"] - 2 * 1080000 * 4 / (d["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * d["value"]
     assert d["config5_strong"]["observations"] == 10800000      # config 5 is cut over the ranks in either mode
+    assert "config4_weak" not in d                              # it is the headline here
