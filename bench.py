@@ -148,10 +148,28 @@ def homography_bench(cvx_amd, torch, device, with_cpu, n=CAMERAS * VIEWS_PER_CAM
         b.run()
     dt = (time.perf_counter() - t) / reps
     Hf, info, ret = b.get()
+    # the step before it in the reference's flow, HomographyEstimator::solve (the normalised DLT, homography.cpp:46-93),
+    # and both in a row with the estimates staying on the device
+    b.dlt(fetch=False)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        b.dlt(fetch=False)
+    dt_dlt = (time.perf_counter() - t) / reps
+    t = time.perf_counter()
+    for _ in range(reps):
+        b.dlt(fetch=False)
+        b.run()
+    dt_both = (time.perf_counter() - t) / reps
+    Hd = b.dlt()
+    res = b.residuals()
     b.close()
     out = {"problems": n, "point_pairs_per_problem": P, "ms_per_batch": 1e3 * dt, "problems_per_s": n / dt,
            "lm_iterations_total": int(info[:, 5].sum()), "residual_evaluations_total": int(info[:, 7].sum()),
-           "converged": int(np.sum(ret > 0)), "kernel": "k_homography_lm (includes the 0.7 MB upload of the starts)"}
+           "converged": int(np.sum(ret > 0)), "kernel": "k_homography_lm (includes the 0.7 MB upload of the starts)",
+           "dlt": {"ms_per_batch": 1e3 * dt_dlt, "problems_per_s": n / dt_dlt, "ms_per_batch_dlt_then_lm": 1e3 * dt_both,
+                   "mean_transfer_residual_px": float(res.mean()),
+                   "kernels": "k_homography_dlt_reduce + k_homography_dlt_finish, estimates left on the device"}}
     if with_cpu:
         from oracle import oracle as orc
         kind = "reference" if orc.levmar_ref() is not None else "port"
@@ -166,6 +184,16 @@ def homography_bench(cvx_amd, torch, device, with_cpu, n=CAMERAS * VIEWS_PER_CAM
         out["cpu_baseline"] = {"value": m / dtc, "unit": "problems/s", "cores": 1, "kind": kind,
                                "sample": "first %d of the %d problems through levmar dlevmar_der, %.2f s" % (m, n, dtc),
                                "bit_identical_to_gpu": "%d of %d" % (same, m)}
+        t = time.perf_counter()
+        worst = 0.0
+        for i in range(m):
+            s = slice(off[i], off[i + 1])
+            _, Ho = orc.homography_dlt(x1[s], y1[s], x2[s], y2[s])
+            worst = max(worst, float(np.max(np.abs(Ho - Hd[i])) / np.max(np.abs(Ho))))
+        dtc = time.perf_counter() - t
+        out["dlt"]["cpu_baseline"] = {"value": m / dtc, "unit": "problems/s", "cores": 1, "kind": "port",
+                                      "sample": "first %d of the %d problems, %.2f s" % (m, n, dtc),
+                                      "worst_relative_difference_to_gpu": worst}
     return out
 
 

@@ -150,6 +150,8 @@ SIGNATURES = {
     "cvx_homography_set": (C.c_int, [C.c_void_p, dp]),
     "cvx_homography_run": (C.c_int, [C.c_void_p, C.c_int, dp]),
     "cvx_homography_get": (C.c_int, [C.c_void_p, dp, dp, ip]),
+    "cvx_homography_dlt": (C.c_int, [C.c_void_p, dp]),
+    "cvx_homography_residuals": (C.c_int, [C.c_void_p, dp, dp]),
     "cvx_calib_data_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "cvx_calib_data_free": (None, [C.c_void_p]),
     "cvx_calib_data_info": (C.c_int, [C.c_void_p, ip, ip, ip, ip, C.POINTER(C.c_int64)]),

@@ -19,10 +19,11 @@ struct cvx_homography {
     int *d_off = nullptr, *d_ret = nullptr;
     float *d_pts = nullptr;          // x1 | y1 | x2 | y2, `total` each
     double *d_H = nullptr, *d_info = nullptr;
+    double *d_W = nullptr, *d_res = nullptr;     // DLT work records / transfer residuals, made on first use
     size_t lds_bytes = 0;
     ~cvx_homography() {
         (void)hipSetDevice(device);
-        for (void *p : {(void *)d_off, (void *)d_ret, (void *)d_pts, (void *)d_H, (void *)d_info})
+        for (void *p : {(void *)d_off, (void *)d_ret, (void *)d_pts, (void *)d_H, (void *)d_info, (void *)d_W, (void *)d_res})
             if (p) (void)hipFree(p);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -60,6 +61,7 @@ extern "C" int cvx_homography_create(int n_problems, const int *off, const float
     CVX_HIP(hipMalloc(&h->d_pts, sizeof(float) * 4 * tp));
     CVX_HIP(hipMalloc(&h->d_H, sizeof(double) * 9 * n_problems));
     CVX_HIP(hipMalloc(&h->d_info, sizeof(double) * 10 * n_problems));
+    CVX_HIP(hipMemsetAsync(h->d_H, 0, sizeof(double) * 9 * n_problems, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_off, off, sizeof(int) * (n_problems + 1), hipMemcpyHostToDevice, h->stream));
     if (total > 0) {
         const float *src[4] = {x1, y1, x2, y2};
@@ -135,4 +137,48 @@ extern "C" int cvx_homography_solve(cvx_homography *h, double *H, int max_iter, 
     st = cvx_homography_run(h, max_iter, opts);
     if (st) return st;
     return cvx_homography_get(h, H, info, ret);
+}
+
+static DltArgs dlt_args(cvx_homography *h) {
+    const size_t tp = (size_t)(h->total > 0 ? h->total : 1);
+    DltArgs a;
+    a.off = h->d_off;
+    a.x1 = h->d_pts; a.y1 = h->d_pts + tp; a.x2 = h->d_pts + 2 * tp; a.y2 = h->d_pts + 3 * tp;
+    a.W = h->d_W; a.H = h->d_H; a.n_problems = h->n;
+    return a;
+}
+
+// HomographyEstimator::solve (homography.cpp:46-93) for every problem of the handle; the estimates stay on the device
+// as the start of cvx_homography_run
+extern "C" int cvx_homography_dlt(cvx_homography *h, double *H) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    if (!h->d_W) CVX_HIP(hipMalloc(&h->d_W, sizeof(double) * DLT_W * h->n));
+    const DltArgs a = dlt_args(h);
+    const size_t lds = dlt_lds_doubles(h->max_points < 4 ? 4 : h->max_points) * sizeof(double);
+    CVX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_homography_dlt_reduce),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CVX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_homography_dlt_finish),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)DLT_FIN_LDS));
+    hipLaunchKernelGGL(k_homography_dlt_reduce, dim3(h->n), dim3(64), lds, h->stream, a);
+    hipLaunchKernelGGL(k_homography_dlt_finish, dim3((h->n + DLT_FIN_THREADS - 1) / DLT_FIN_THREADS), dim3(DLT_FIN_THREADS),
+                       DLT_FIN_LDS, h->stream, a);
+    CVX_HIP(hipGetLastError());
+    if (H) CVX_HIP(hipMemcpyAsync(H, h->d_H, sizeof(double) * 9 * h->n, hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
+}
+
+// HomographyEstimator::residuals (homography.cpp:95-110) of every point pair under its problem's estimate
+extern "C" int cvx_homography_residuals(cvx_homography *h, const double *H, double *res) {
+    if (!h || !res) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    if (h->total == 0) return CVX_OK;
+    if (!h->d_res) CVX_HIP(hipMalloc(&h->d_res, sizeof(double) * h->total));
+    if (H) CVX_HIP(hipMemcpyAsync(h->d_H, H, sizeof(double) * 9 * h->n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_homography_residuals, dim3(h->n), dim3(64), 0, h->stream, dlt_args(h), h->d_res);
+    CVX_HIP(hipGetLastError());
+    CVX_HIP(hipMemcpyAsync(res, h->d_res, sizeof(double) * h->total, hipMemcpyDeviceToHost, h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));
+    return CVX_OK;
 }

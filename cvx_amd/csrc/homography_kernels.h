@@ -360,4 +360,267 @@ __global__ __launch_bounds__(64) void k_homography_lm(HomArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// HomographyEstimator::solve (the normalised DLT, /root/reference/modules/calib/src/homography.cpp:17-93) and
+// HomographyEstimator::residuals (:95-110) for the same batches -- the steps either side of solveLM in the reference's
+// flow (solveRansac -> inliers -> solveLM).  Two launches:
+//   k_homography_dlt_reduce   one wave per problem: normalize_points in the reference's float arithmetic and summation
+//                             order, the 2N x 9 constraint matrix in LDS, Householder QR down to its 9 x 9 triangle
+//   k_homography_dlt_finish   one LANE per problem: one-sided Jacobi SVD of the triangle (the right singular vector of
+//                             the smallest singular value = JacobiSVD(A, ComputeFullV).matrixV().col(8) up to sign and
+//                             rounding; Eigen is un-vendored), H = T2^-1 Hn T1, H /= H(2,2)
+// -----------------------------------------------------------------------------------------
+struct DltArgs {
+    const int *off;
+    const float *x1, *y1, *x2, *y2;
+    double *W;          // [n_problems][DLT_W] : R (81, row-major, zero below the diagonal) | cx1 cy1 s1 cx2 cy2 s2
+    double *H;          // [n_problems][9]
+    int n_problems;
+};
+constexpr int DLT_W = 88;
+constexpr int DLT_PER_LANE = 16;            // 64 x 16 = CVX_HOMOGRAPHY_MAX_POINTS
+__host__ __device__ inline size_t dlt_lds_doubles(int n_points) { return (size_t)18 * n_points + HOM_SCRATCH; }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double hom_dpp_take(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the wave by data-parallel-primitive moves, the same value on every lane
+__device__ __forceinline__ double hom_wave_sum(double v) {
+    v += hom_dpp_take<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v += hom_dpp_take<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v += hom_dpp_take<0x141, 0xF>(v);       // row_half_mirror
+    v += hom_dpp_take<0x140, 0xF>(v);       // row_mirror
+    v += hom_dpp_take<0x142, 0xA>(v);       // row_bcast:15 into rows 1 and 3
+    v += hom_dpp_take<0x143, 0xC>(v);       // row_bcast:31 into rows 2 and 3
+    return bcast(v, 63);
+}
+
+// normalize_points' sums for one coordinate array (homography.cpp:20-30), by ONE lane in the reference's order: cv::Point2f
+// arithmetic is float, so the order is part of the result.  Eight loads in flight per step of the chain.
+__device__ __forceinline__ float dlt_serial_sum(const float *v, int stride, int N) {
+    float s = 0.0f;
+    int i = 0;
+    for (; i + 8 <= N; i += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[(i + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = s + t[j];
+    }
+    for (; i < N; ++i) s = s + v[i * stride];
+    return s;
+}
+
+__global__ __launch_bounds__(64) void k_homography_dlt_reduce(DltArgs a) {
+    extern __shared__ double4 hom_lds_raw[];
+    double *lds = reinterpret_cast<double *>(hom_lds_raw);
+    const int prob = blockIdx.x, lane = threadIdx.x;
+    const int o0 = a.off[prob], N = a.off[prob + 1] - o0, m = 2 * N;
+    if (N < 4) return;
+    float *P = reinterpret_cast<float *>(lds);                       // x1 y1 x2 y2 per point, overlaid by A later
+    double *S = lds + 18 * (size_t)N;                                // scratch behind A
+    float4 mine[DLT_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < DLT_PER_LANE; ++k) {
+        const int i = lane + 64 * k;
+        mine[k] = (i < N) ? make_float4(a.x1[o0 + i], a.y1[o0 + i], a.x2[o0 + i], a.y2[o0 + i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < N) reinterpret_cast<float4 *>(P)[i] = mine[k];
+    }
+    __syncthreads();
+    // centres: lanes 0..3 each sum one coordinate in point order; then the mean squared distances: lanes 0 and 1
+    float *Sf = reinterpret_cast<float *>(S);
+    if (lane < 4) Sf[lane] = dlt_serial_sum(P + lane, 4, N) / (float)N;
+    __syncthreads();
+    if (lane < 2) {
+        // float products and sums one by one, as the host compiler leaves them without FMA contraction (the intrinsics of
+        // the __f*_rn family are plain operators here, which the device compiler would fuse)
+#pragma clang fp contract(off)
+        const float cx = Sf[2 * lane], cy = Sf[2 * lane + 1];
+        const float *px = P + 2 * lane;
+        float nrm = 0.0f;
+        int i = 0;
+        for (; i + 8 <= N; i += 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dx = px[4 * (i + j)] - cx, dy = px[4 * (i + j) + 1] - cy;
+                const float xx = dx * dx, yy = dy * dy;
+                t[j] = xx + yy;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nrm = nrm + t[j];
+        }
+        for (; i < N; ++i) {
+            const float dx = px[4 * i] - cx, dy = px[4 * i + 1] - cy;
+            const float xx = dx * dx, yy = dy * dy;
+            const float d = xx + yy;
+            nrm = nrm + d;
+        }
+        nrm = nrm / (float)N;
+        // sqrt(2.0) / sqrt(nrm): the float overload (:32); correctly rounded square roots and divisions (the compiler's
+        // default for HIP, -fhip-fp32-correctly-rounded-divide-sqrt)
+        S[4 + lane] = sqrt(2.0) / (double)sqrtf(nrm);
+    }
+    __syncthreads();
+    const float cx1 = Sf[0], cy1 = Sf[1], cx2 = Sf[2], cy2 = Sf[3];
+    const double s1 = S[4], s2 = S[5];
+    __syncthreads();        // P is dead from here on: A takes its place
+    double *A = lds;
+#pragma unroll
+    for (int k = 0; k < DLT_PER_LANE; ++k) {
+        const int i = lane + 64 * k;
+        if (i < N) {
+            // (p - center) * scale: a float difference, a double product rounded to float (homography.cpp:40)
+            const double u1 = (double)(float)((double)(mine[k].x - cx1) * s1), v1 = (double)(float)((double)(mine[k].y - cy1) * s1);
+            const double u2 = (double)(float)((double)(mine[k].z - cx2) * s2), v2 = (double)(float)((double)(mine[k].w - cy2) * s2);
+            double *r0 = A + 18 * (size_t)i, *r1 = r0 + 9;
+            r0[0] = u1; r0[1] = v1; r0[2] = 1.0; r0[3] = 0.0; r0[4] = 0.0; r0[5] = 0.0; r0[6] = -u2 * u1; r0[7] = -u2 * v1; r0[8] = -u2;
+            r1[0] = 0.0; r1[1] = 0.0; r1[2] = 0.0; r1[3] = -u1; r1[4] = -v1; r1[5] = -1.0; r1[6] = v2 * u1; r1[7] = v2 * v1; r1[8] = v2;
+        }
+    }
+    __syncthreads();
+    // Householder QR, rows dealt to the lanes (row i on lane i % 64): reflector k from column k's rows >= k, applied to
+    // the columns right of it; one wave sum for the norm, one per remaining column for the dot products
+    const int kmax = m < 9 ? m : 9;
+    for (int k = 0; k < kmax; ++k) {
+        double part = 0.0;
+        for (int i = k + ((lane - k) & 63); i < m; i += 64) { const double v = A[9 * (size_t)i + k]; part += v * v; }
+        const double ss = hom_wave_sum(part);
+        const double akk = A[9 * (size_t)k + k];
+        __syncthreads();
+        if (ss > 0.0) {
+            const double alpha = akk > 0.0 ? -sqrt(ss) : sqrt(ss);
+            const double beta = 1.0 / (ss - akk * alpha);                 // 2 / v^T v with v = x - alpha e_k
+            if (lane == (k & 63)) A[9 * (size_t)k + k] = akk - alpha;    // v_k (the other v_i are the column's entries)
+            __syncthreads();
+            double d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = 0.0;
+            for (int i = k + ((lane - k) & 63); i < m; i += 64) {
+                const double *row = A + 9 * (size_t)i;
+                const double v = row[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (k + 1 + j < 9) d[j] += v * row[k + 1 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k + 1 + j < 9) d[j] = hom_wave_sum(d[j]) * beta;
+            for (int i = k + ((lane - k) & 63); i < m; i += 64) {
+                double *row = A + 9 * (size_t)i;
+                const double v = row[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (k + 1 + j < 9) row[k + 1 + j] -= d[j] * v;
+            }
+            __syncthreads();
+            if (lane == (k & 63)) A[9 * (size_t)k + k] = alpha;
+        }
+        __syncthreads();
+    }
+    double *W = a.W + (size_t)prob * DLT_W;
+    for (int e = lane; e < 81; e += 64) {
+        const int r = e / 9, c = e - 9 * r;
+        W[e] = (r < m && c >= r) ? A[9 * (size_t)r + c] : 0.0;
+    }
+    if (lane == 0) { W[81] = cx1; W[82] = cy1; W[83] = s1; W[84] = cx2; W[85] = cy2; W[86] = s2; W[87] = 0.0; }
+}
+
+// 3 x 3 inverse as cofactors times the reciprocal of the determinant (Eigen's fixed-size path)
+__device__ __forceinline__ void hom_inverse3(const double M[9], double R[9]) {
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;
+    R[0] = c00 * id; R[1] = (M[2] * M[7] - M[1] * M[8]) * id; R[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    R[3] = c01 * id; R[4] = (M[0] * M[8] - M[2] * M[6]) * id; R[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    R[6] = c02 * id; R[7] = (M[1] * M[6] - M[0] * M[7]) * id; R[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+__device__ __forceinline__ void hom_mul3(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+
+// one lane per problem; R and V live in LDS element-major ([element][lane]: consecutive lanes, consecutive banks)
+constexpr int DLT_FIN_THREADS = 64;
+constexpr size_t DLT_FIN_LDS = sizeof(double) * 2 * 81 * DLT_FIN_THREADS;
+__global__ __launch_bounds__(DLT_FIN_THREADS) void k_homography_dlt_finish(DltArgs a) {
+    extern __shared__ double4 hom_lds_raw[];       // 2 x 81 x 64 doubles: above the static limit
+    double (*Rm)[DLT_FIN_THREADS] = reinterpret_cast<double (*)[DLT_FIN_THREADS]>(hom_lds_raw);
+    double (*Vm)[DLT_FIN_THREADS] = Rm + 81;
+    const int lane = threadIdx.x, prob = blockIdx.x * DLT_FIN_THREADS + lane;
+    const bool live = prob < a.n_problems && (a.off[prob + 1] - a.off[prob]) >= 4;
+    if (!live) return;              // no barrier below: lanes are independent
+    const double *W = a.W + (size_t)prob * DLT_W;
+    double fro = 0.0;
+    for (int e = 0; e < 81; ++e) {
+        const double v = W[e];
+        Rm[e][lane] = v; Vm[e][lane] = (e % 10 == 0) ? 1.0 : 0.0;
+        fro += v * v;
+    }
+    const double tiny = 1e-28 * fro;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                double cp[9], cq[9], al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { cp[i] = Rm[9 * i + p][lane]; cq[i] = Rm[9 * i + q][lane]; }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { al += cp[i] * cp[i]; be += cq[i] * cq[i]; ga += cp[i] * cq[i]; }
+                if (!(fabs(ga) > 1e-15 * sqrt(al * be)) || al <= tiny || be <= tiny) continue;
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    Rm[9 * i + p][lane] = c * cp[i] - sn * cq[i]; Rm[9 * i + q][lane] = sn * cp[i] + c * cq[i];
+                    const double vp = Vm[9 * i + p][lane], vq = Vm[9 * i + q][lane];
+                    Vm[9 * i + p][lane] = c * vp - sn * vq; Vm[9 * i + q][lane] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    int best = 0;
+    double least = 0.0;
+    for (int j = 0; j < 9; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const double v = Rm[9 * i + j][lane]; s += v * v; }
+        if (j == 0 || s < least) { least = s; best = j; }
+    }
+    double v[9], T1[9], T2[9], T2i[9], M[9], Hh[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = Vm[9 * i + best][lane];
+    const double cx1 = W[81], cy1 = W[82], s1 = W[83], cx2 = W[84], cy2 = W[85], s2 = W[86];
+    T1[0] = s1; T1[1] = 0.0; T1[2] = -s1 * cx1; T1[3] = 0.0; T1[4] = s1; T1[5] = -s1 * cy1; T1[6] = 0.0; T1[7] = 0.0; T1[8] = 1.0;
+    T2[0] = s2; T2[1] = 0.0; T2[2] = -s2 * cx2; T2[3] = 0.0; T2[4] = s2; T2[5] = -s2 * cy2; T2[6] = 0.0; T2[7] = 0.0; T2[8] = 1.0;
+    hom_inverse3(T2, T2i);
+    hom_mul3(T2i, v, M);
+    hom_mul3(M, T1, Hh);
+    const double h22 = Hh[8];
+    double *Ho = a.H + (size_t)prob * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ho[i] = Hh[i] / h22;
+}
+
+// HomographyEstimator::residuals (homography.cpp:95-110): one wave per problem, a point pair per lane and turn
+__global__ __launch_bounds__(64) void k_homography_residuals(DltArgs a, double *res) {
+    const int prob = blockIdx.x, lane = threadIdx.x;
+    const int o0 = a.off[prob], N = a.off[prob + 1] - o0;
+    double H[9], Hi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] = a.H[(size_t)prob * 9 + i];
+    hom_inverse3(H, Hi);
+    for (int i = lane; i < N; i += 64) {
+        const double x = a.x1[o0 + i], y = a.y1[o0 + i], z = a.x2[o0 + i], w = a.y2[o0 + i];
+        const double w1 = H[6] * x + H[7] * y + H[8], w2 = Hi[6] * z + Hi[7] * w + Hi[8];
+        const double e0 = (H[0] * x + H[1] * y + H[2]) / w1 - z, e1 = (H[3] * x + H[4] * y + H[5]) / w1 - w;
+        const double f0 = (Hi[0] * z + Hi[1] * w + Hi[2]) / w2 - x, f1 = (Hi[3] * z + Hi[4] * w + Hi[5]) / w2 - y;
+        res[o0 + i] = sqrt(e0 * e0 + e1 * e1) + sqrt(f0 * f0 + f1 * f1);
+    }
+}
+
 }  // namespace cvxhom

@@ -309,6 +309,21 @@ class HomographyBatch:
         check(lib().cvx_homography_get(self.h, pd(H), pd(info), pi(ret)), "cvx_homography_get")
         return H, info, ret
 
+    def dlt(self, fetch=True):
+        """HomographyEstimator::solve (homography.cpp:46-93) of every problem; the estimates stay on the device as the
+        start of run()"""
+        H = np.zeros((self.n, 9)) if fetch else None
+        check(lib().cvx_homography_dlt(self.h, pd(H) if fetch else None), "cvx_homography_dlt")
+        return H
+
+    def residuals(self, H=None):
+        """HomographyEstimator::residuals (homography.cpp:95-110) per point pair; H None = the handle's estimates"""
+        res = np.zeros(int(self.off[-1]))
+        if H is not None:
+            H = np.ascontiguousarray(H, dtype=np.float64).reshape(self.n, 9)
+        check(lib().cvx_homography_residuals(self.h, pd(H) if H is not None else None, pd(res)), "cvx_homography_residuals")
+        return res
+
 
 class ToolBA:
     """cvx_toolba handle: bundleAdjustment of tools/hand_eye_registration.cpp:144-238 on one GPU."""

@@ -372,6 +372,18 @@ int cvx_homography_solve(cvx_homography *h, double *H, int max_iter, const doubl
 int cvx_homography_set(cvx_homography *h, const double *H);
 int cvx_homography_run(cvx_homography *h, int max_iter, const double *opts);
 int cvx_homography_get(cvx_homography *h, double *H, double *info, int *ret);
+/* The steps either side of solveLM in the reference's flow (solveRansac -> inliers -> solveLM), on the same handle:
+ * HomographyEstimator::solve (homography.cpp:46-93): the normalised DLT of every problem -- normalize_points
+ * (:17-42) in the reference's float arithmetic and summation order, the 2N x 9 constraint matrix (:58-83), the right
+ * singular vector of its smallest singular value (:86-88; Eigen's JacobiSVD is un-vendored: Householder QR to the 9 x 9
+ * triangle, then a one-sided Jacobi SVD), H = T2^-1 Hn T1, H /= H(2,2) (:91-92).  The estimates stay on the device as
+ * the start of cvx_homography_run; H (n_problems x 9 row-major, or NULL) receives them.  A problem with fewer than 4
+ * pairs keeps its current estimate (zeros after create). */
+int cvx_homography_dlt(cvx_homography *h, double *H);
+/* HomographyEstimator::residuals (homography.cpp:95-110): per point pair |hn(H p1) - p2| + |hn(H^-1 p2) - p1|, res in
+ * the order of the point arrays (off[n_problems] doubles).  H: n_problems x 9 row-major, or NULL = the handle's current
+ * estimates (what cvx_homography_dlt / _run / _set left). */
+int cvx_homography_residuals(cvx_homography *h, const double *H, double *res);
 
 /* ------------------------------------------------------------------------ */
 /* On-disk formats either side of the path (host only)   */

@@ -268,6 +268,88 @@ bool homography_solve_lm(const std::vector<Point> &pts1, const std::vector<Point
 }
 
 // ------------------------------------------------------------------------------------------
+// void HomographyEstimator::solve(pts1, pts2, H)                 homography.cpp:46-93   (the normalised DLT)
+// void HomographyEstimator::residuals(pts1, pts2, H, res)        homography.cpp:95-110
+// for a batch of views.  With refine_iterations > 0, solve_batch goes on to solveLM over ALL pairs of every view
+// (inliers = everything) without the estimates leaving the device.
+// ------------------------------------------------------------------------------------------
+namespace detail {
+template <class Point>
+inline cvx_homography *homography_handle(const std::vector<const std::vector<Point> *> &pts1,
+                                         const std::vector<const std::vector<Point> *> &pts2, std::vector<int> &off,
+                                         int device, void *stream) {
+    const size_t n = pts1.size();
+    if (pts2.size() != n) throw std::invalid_argument("homography batch: size mismatch");
+    off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (pts1[i]->size() != pts2[i]->size()) throw std::invalid_argument("homography batch: pts1 / pts2 differ in length");   // :47
+        off[i + 1] = off[i] + (int)pts1[i]->size();
+    }
+    std::vector<float> x1(off[n]), y1(off[n]), x2(off[n]), y2(off[n]);
+    for (size_t i = 0; i < n; ++i)
+        for (size_t k = 0; k < pts1[i]->size(); ++k) {
+            const int o = off[i] + (int)k;
+            x1[o] = (*pts1[i])[k].x; y1[o] = (*pts1[i])[k].y; x2[o] = (*pts2[i])[k].x; y2[o] = (*pts2[i])[k].y;
+        }
+    cvx_homography *hh = nullptr;
+    check(cvx_homography_create((int)n, off.data(), x1.data(), y1.data(), x2.data(), y2.data(), device, stream, &hh),
+          "cvx_homography_create");
+    return hh;
+}
+}  // namespace detail
+
+template <class Point, class Mat3>
+void homography_solve_batch(const std::vector<const std::vector<Point> *> &pts1,
+                            const std::vector<const std::vector<Point> *> &pts2, std::vector<Mat3> &H,
+                            int refine_iterations = 0, int device = 0, void *stream = nullptr) {
+    const size_t n = pts1.size();
+    H.resize(n);
+    if (n == 0) return;
+    std::vector<int> off;
+    cvx_homography *hh = detail::homography_handle(pts1, pts2, off, device, stream);
+    std::vector<double> h(9 * n, 0.0);
+    int st = cvx_homography_dlt(hh, h.data());
+    if (!st && refine_iterations > 0) {
+        st = cvx_homography_run(hh, refine_iterations, nullptr);
+        if (!st) st = cvx_homography_get(hh, h.data(), nullptr, nullptr);
+    }
+    cvx_homography_destroy(hh);
+    check(st, "cvx_homography_dlt");
+    for (size_t i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) H[i](r, c) = h[9 * i + 3 * r + c];
+}
+
+template <class Point, class Mat3>
+void homography_solve(const std::vector<Point> &pts1, const std::vector<Point> &pts2, Mat3 &H, int device = 0,
+                      void *stream = nullptr) {
+    std::vector<Mat3> Hs;
+    homography_solve_batch<Point, Mat3>({&pts1}, {&pts2}, Hs, 0, device, stream);
+    H = Hs[0];
+}
+
+// res[i] receives view i's residuals (the reference appends to `res`: one vector per view here)
+template <class Point, class Mat3>
+void homography_residuals_batch(const std::vector<const std::vector<Point> *> &pts1,
+                                const std::vector<const std::vector<Point> *> &pts2, const std::vector<Mat3> &H,
+                                std::vector<std::vector<double>> &res, int device = 0, void *stream = nullptr) {
+    const size_t n = pts1.size();
+    if (H.size() != n) throw std::invalid_argument("homography batch: size mismatch");
+    res.assign(n, std::vector<double>());
+    if (n == 0) return;
+    std::vector<int> off;
+    cvx_homography *hh = detail::homography_handle(pts1, pts2, off, device, stream);
+    std::vector<double> h(9 * n), r(off[n] > 0 ? off[n] : 1);
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) h[9 * i + 3 * a + c] = H[i](a, c);
+    const int st = cvx_homography_residuals(hh, h.data(), r.data());
+    cvx_homography_destroy(hh);
+    check(st, "cvx_homography_residuals");
+    for (size_t i = 0; i < n; ++i) res[i].assign(r.begin() + off[i], r.begin() + off[i + 1]);
+}
+
+// ------------------------------------------------------------------------------------------
 // void bundleAdjustment(cam, data, gripper_to_base, pose, off, coords)
 //     tools/hand_eye_registration.cpp:144-238 (= tools/camera_ba.cpp:146-240)
 // pose: in, the initial sensor pose as the tool passes it (:431-432, 439); out, the refined pose INVERTED as :229-230

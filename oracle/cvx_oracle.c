@@ -1538,6 +1538,145 @@ int orc_homography_lm(void *engine, int n, const float *x1, const float *y1, con
 }
 
 /* ======================================================================== */
+/* homography DLT and transfer residuals: homography.cpp:17-110                */
+/* ======================================================================== */
+/* normalize_points (homography.cpp:17-42).  The reference sums in cv::Point2f arithmetic: the centre and the mean
+ * squared distance are float sums in point order (Point_::dot is a float expression), `sqrt(nrm)` with a float argument
+ * under `using namespace std` is the float overload, the scale is a double, and `(p - center) * scale` is
+ * Point2f * double: the double product rounded back to float (OpenCV's operator*). */
+static void hom_normalize(int n, const float *x, const float *y, float *nx, float *ny, double T[9]) {
+    float cx = 0.0f, cy = 0.0f;
+    for (int i = 0; i < n; ++i) { cx += x[i]; cy += y[i]; }
+    cx /= (float)n; cy /= (float)n;
+    float nrm = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const float dx = x[i] - cx, dy = y[i] - cy;
+        const float d = dx * dx + dy * dy;
+        nrm += d;
+    }
+    nrm /= (float)n;
+    const double scale = sqrt(2.0) / (double)sqrtf(nrm);
+    T[0] = scale; T[1] = 0.0; T[2] = -scale * cx;
+    T[3] = 0.0; T[4] = scale; T[5] = -scale * cy;
+    T[6] = 0.0; T[7] = 0.0; T[8] = 1.0;
+    for (int i = 0; i < n; ++i) {
+        nx[i] = (float)((double)(x[i] - cx) * scale);
+        ny[i] = (float)((double)(y[i] - cy) * scale);
+    }
+}
+
+/* Matrix3d::inverse(): cofactors times the reciprocal of the determinant (Eigen's fixed-size 3x3 path, un-vendored:
+ * from its published source; the order of the additions inside a cofactor is not pinned) */
+static void hom_inverse3(const double M[9], double R[9]) {
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;
+    R[0] = c00 * id; R[1] = (M[2] * M[7] - M[1] * M[8]) * id; R[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    R[3] = c01 * id; R[4] = (M[0] * M[8] - M[2] * M[6]) * id; R[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    R[6] = c02 * id; R[7] = (M[1] * M[6] - M[0] * M[7]) * id; R[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+static void hom_mul3(const double A[9], const double B[9], double C[9]) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+
+/* The right singular vector of the smallest singular value of A (m x 9, row-major, destroyed): what
+ * JacobiSVD(A, ComputeFullV).matrixV().col(8) is up to sign and rounding (homography.cpp:86-88; Eigen un-vendored).
+ * One-sided Jacobi (Hestenes): plane rotations from the right make A's columns orthogonal, cyclic by rows, until a
+ * sweep rotates nothing (60 at most); V collects the rotations; the column of smallest norm wins.  Returns the number of sweeps. */
+int orc_null_vector9(int m, double *A, double v[9]) {
+    double V[81];
+    for (int i = 0; i < 81; ++i) V[i] = (i % 10 == 0) ? 1.0 : 0.0;
+    /* a column whose norm has fallen below 1e-14 |A|_F is the null direction of a rank-deficient A (four point pairs:
+     * eight rows): it is left alone, its inner products are rounding noise */
+    double fro = 0.0;
+    for (int i = 0; i < 9 * m; ++i) fro += A[i] * A[i];
+    const double tiny = 1e-28 * fro;
+    int sweeps = 0;
+    for (; sweeps < 60; ++sweeps) {
+        int rotated = 0;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int i = 0; i < m; ++i) {
+                    const double ap = A[9 * i + p], aq = A[9 * i + q];
+                    al += ap * ap; be += aq * aq; ga += ap * aq;
+                }
+                if (!(fabs(ga) > 1e-15 * sqrt(al * be)) || al <= tiny || be <= tiny) continue;
+                rotated = 1;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < m; ++i) {
+                    const double ap = A[9 * i + p], aq = A[9 * i + q];
+                    A[9 * i + p] = c * ap - sn * aq; A[9 * i + q] = sn * ap + c * aq;
+                }
+                for (int i = 0; i < 9; ++i) {
+                    const double vp = V[9 * i + p], vq = V[9 * i + q];
+                    V[9 * i + p] = c * vp - sn * vq; V[9 * i + q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    int best = 0;
+    double least = 0.0;
+    for (int j = 0; j < 9; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += A[9 * i + j] * A[9 * i + j];
+        if (j == 0 || s < least) { least = s; best = j; }
+    }
+    for (int i = 0; i < 9; ++i) v[i] = V[9 * i + best];
+    return sweeps;
+}
+
+/* the constraint matrix of homography.cpp:58-83 over the normalised points: 2n x 9 row-major */
+void orc_homography_dlt_matrix(int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                               double *A, double T1[9], double T2[9]) {
+    float *buf = malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+    float *a = buf, *b = buf + n, *c = buf + 2 * n, *d = buf + 3 * n;
+    hom_normalize(n, x1, y1, a, b, T1);
+    hom_normalize(n, x2, y2, c, d, T2);
+    for (int i = 0; i < n; ++i) {
+        const double u1 = a[i], v1 = b[i], u2 = c[i], v2 = d[i];
+        double *r0 = A + (size_t)18 * i, *r1 = r0 + 9;
+        r0[0] = u1; r0[1] = v1; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -u2 * u1; r0[7] = -u2 * v1; r0[8] = -u2;
+        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = -u1; r1[4] = -v1; r1[5] = -1; r1[6] = v2 * u1; r1[7] = v2 * v1; r1[8] = v2;
+    }
+    free(buf);
+}
+
+/* HomographyEstimator::solve (homography.cpp:46-93): H row-major, H(2,2) = 1.  Returns the sweeps of the SVD, -1 and
+ * H untouched when n < 4 (the reference asserts nothing there; eight equations do not determine H). */
+int orc_homography_dlt(int n, const float *x1, const float *y1, const float *x2, const float *y2, double H[9]) {
+    if (n < 4) return -1;
+    double *A = malloc(sizeof(double) * 18 * (size_t)n), T1[9], T2[9], v[9], T2i[9], M[9];
+    orc_homography_dlt_matrix(n, x1, y1, x2, y2, A, T1, T2);
+    const int sweeps = orc_null_vector9(2 * n, A, v);
+    free(A);
+    /* H_t.transpose() of the column-major map of the null vector = its row-major reading (:89-91) */
+    hom_inverse3(T2, T2i);
+    hom_mul3(T2i, v, M);
+    hom_mul3(M, T1, H);
+    const double h22 = H[8];
+    for (int i = 0; i < 9; ++i) H[i] /= h22;
+    return sweeps;
+}
+
+/* HomographyEstimator::residuals (homography.cpp:95-110): per pair |hn(H p1) - p2| + |hn(H^-1 p2) - p1| */
+void orc_homography_residuals(int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                              const double H[9], double *res) {
+    double Hi[9];
+    hom_inverse3(H, Hi);
+    for (int i = 0; i < n; ++i) {
+        const double a = x1[i], b = y1[i], c = x2[i], d = y2[i];
+        const double w1 = H[6] * a + H[7] * b + H[8], w2 = Hi[6] * c + Hi[7] * d + Hi[8];
+        const double e0 = (H[0] * a + H[1] * b + H[2]) / w1 - c, e1 = (H[3] * a + H[4] * b + H[5]) / w1 - d;
+        const double f0 = (Hi[0] * c + Hi[1] * d + Hi[2]) / w2 - a, f1 = (Hi[3] * c + Hi[4] * d + Hi[5]) / w2 - b;
+        res[i] = sqrt(e0 * e0 + e1 * e1) + sqrt(f0 * f0 + f1 * f1);
+    }
+}
+
+/* ======================================================================== */
 /* tool-level bundle adjustment: hand_eye_registration.cpp:48-238             */
 /* ======================================================================== */
 /* ceres::QuaternionRotatePoint (Ceres rotation.h, un-vendored: restated from the published 1.x source): the

@@ -221,6 +221,16 @@ void orc_homography_errors(int n, const float *x1, const float *y1, const float 
                            const double h[8], double *e /* 2n */);
 void orc_homography_jacobian(int n, const float *x1, const float *y1, const double h[8], double *J /* 2n x 8 */);
 
+/* ---- HomographyEstimator::solve (normalised DLT) and ::residuals, homography.cpp:17-110 ---- */
+/* PARITY UNPINNED: the reference holds no vectors for these, and the SVD is Eigen's (un-vendored): restated as a
+ * one-sided Jacobi SVD, pinned against LAPACK's SVD of the same matrix in tests/test_homography_oracle.py. */
+int orc_homography_dlt(int n, const float *x1, const float *y1, const float *x2, const float *y2, double H[9]);
+void orc_homography_dlt_matrix(int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                               double *A /* 2n x 9 */, double T1[9], double T2[9]);
+int orc_null_vector9(int m, double *A /* m x 9, destroyed */, double v[9]);
+void orc_homography_residuals(int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                              const double H[9], double *res /* n */);
+
 /* LU solve of the no-LAPACK levmar build (Axb_core.c:992-1139); A, b preserved */
 int orc_lu_solve(int n, const double *A, const double *b, double *x);
 /* dense SPD solve used by the drivers (Cholesky); returns 0 on failure */

@@ -134,6 +134,12 @@ def lib():
         L.orc_homography_lm.restype = C.c_int
         L.orc_homography_errors.argtypes = [C.c_int, fp, fp, fp, fp, dp, dp]
         L.orc_homography_jacobian.argtypes = [C.c_int, fp, fp, dp, dp]
+        L.orc_homography_dlt.argtypes = [C.c_int, fp, fp, fp, fp, dp]
+        L.orc_homography_dlt.restype = C.c_int
+        L.orc_homography_dlt_matrix.argtypes = [C.c_int, fp, fp, fp, fp, dp, dp, dp]
+        L.orc_null_vector9.argtypes = [C.c_int, dp, dp]
+        L.orc_null_vector9.restype = C.c_int
+        L.orc_homography_residuals.argtypes = [C.c_int, fp, fp, fp, fp, dp, dp]
         _LIB = L
     return _LIB
 
@@ -342,3 +348,35 @@ def homography_lm(x1, y1, x2, y2, h, itmax=100, opts=LEVMAR_OPTS, engine="restat
         fn = C.cast(R.dlevmar_der, C.c_void_p)
     ret = lib().orc_homography_lm(fn, len(x1), _fp(x1), _fp(y1), _fp(x2), _fp(y2), _dp(hh), int(itmax), _dp(o), _dp(info))
     return ret, hh, info
+
+
+def homography_dlt(x1, y1, x2, y2):
+    """HomographyEstimator::solve (homography.cpp:46-93) on one problem: (sweeps of the SVD or -1, H[9] row-major)"""
+    x1, y1, x2, y2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (x1, y1, x2, y2))
+    H = np.zeros(9)
+    ret = lib().orc_homography_dlt(len(x1), _fp(x1), _fp(y1), _fp(x2), _fp(y2), _dp(H))
+    return ret, H
+
+
+def homography_dlt_matrix(x1, y1, x2, y2):
+    """the constraint matrix (2n x 9) over the normalised points, and the two normalising transforms"""
+    x1, y1, x2, y2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (x1, y1, x2, y2))
+    A = np.zeros((2 * len(x1), 9)); T1 = np.zeros(9); T2 = np.zeros(9)
+    lib().orc_homography_dlt_matrix(len(x1), _fp(x1), _fp(y1), _fp(x2), _fp(y2), _dp(A), _dp(T1), _dp(T2))
+    return A, T1.reshape(3, 3), T2.reshape(3, 3)
+
+
+def null_vector9(A):
+    A = np.array(A, dtype=np.float64, order="C")
+    v = np.zeros(9)
+    sweeps = lib().orc_null_vector9(A.shape[0], _dp(A), _dp(v))
+    return v, sweeps
+
+
+def homography_residuals(x1, y1, x2, y2, H):
+    """HomographyEstimator::residuals (homography.cpp:95-110)"""
+    x1, y1, x2, y2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (x1, y1, x2, y2))
+    H = np.ascontiguousarray(np.asarray(H, dtype=np.float64).reshape(-1))
+    res = np.zeros(len(x1))
+    lib().orc_homography_residuals(len(x1), _fp(x1), _fp(y1), _fp(x2), _fp(y2), _dp(H), _dp(res))
+    return res

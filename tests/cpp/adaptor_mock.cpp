@@ -124,6 +124,22 @@ int main() {
     std::printf("], \"hom_ok\": %d, \"hom\": [", ok ? 1 : 0);
     for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", H.m[i]);
     std::printf("], ");
+    // HomographyEstimator::solve (the DLT) and ::residuals on the same view, all pairs
+    Mat3 Hd;
+    std::vector<std::vector<double>> hres;
+    try {
+        cvx_amd::homography_solve(b1, b2, Hd);
+        std::vector<Mat3> Hs(1, Hd);
+        cvx_amd::homography_residuals_batch<Pt2f, Mat3>({&b1}, {&b2}, Hs, hres);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 8;
+    }
+    std::printf("\"hom_dlt\": [");
+    for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", Hd.m[i]);
+    std::printf("], \"hom_dlt_res\": [");
+    for (size_t i = 0; i < hres[0].size(); ++i) std::printf("%s%.17g", i ? ", " : "", hres[0][i]);
+    std::printf("], ");
 
     // bundleAdjustment of tools/hand_eye_registration.cpp on the same detections: the "gripper" transforms are
     // chosen so that pose * trans_v equals each view's ground-truth board pose; start = a perturbed pose, inverted

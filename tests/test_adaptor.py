@@ -71,6 +71,14 @@ def test_adaptor_refine_and_handeye_match_oracle(orc):
     r, h, info = orc.homography_lm(x1, y1, x2, y2, out["hom_start"])
     assert out["hom_ok"] == 1 and r > 0
     assert out["hom"][:8] == h.tolist() and out["hom"][8] == 1.0
+    # HomographyEstimator::solve / ::residuals over all pairs of view 0
+    pid = d["point_id"][o0:o1]
+    a1 = d["points_init"][pid, 0].astype(np.float32); b1 = d["points_init"][pid, 1].astype(np.float32)
+    a2 = d["obs_x"][o0:o1].astype(np.float32); b2 = d["obs_y"][o0:o1].astype(np.float32)
+    rd, Hd = orc.homography_dlt(a1, b1, a2, b2)
+    assert rd > 0 and np.max(np.abs(np.array(out["hom_dlt"]) - Hd)) <= 1e-13 * np.max(np.abs(Hd))
+    ro = orc.homography_residuals(a1, b1, a2, b2, np.array(out["hom_dlt"]))
+    assert np.max(np.abs(np.array(out["hom_dlt_res"]) - ro)) <= 1e-11 * max(1.0, np.max(ro))
     # tool-level bundle adjustment: same problem rebuilt here and solved by the oracle
     from oracle import oracle as orc_mod
     wg = np.array([0.1, -0.2, 0.15]); tg = np.array([10.0, -20.0, 30.0])

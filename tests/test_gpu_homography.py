@@ -9,7 +9,7 @@ import cvx_amd
 from cvx_amd import capi
 from cvx_amd.problem import HomographyBatch
 from conftest import load_golden
-from test_helpers import homography_batch
+from test_helpers import homography_batch, homography_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -105,3 +105,116 @@ def test_custom_options_and_iteration_cap(orc):
         s = slice(off[i], off[i + 1])
         r, h, inf = orc.homography_lm(x1[s], y1[s], x2[s], y2[s], H0[i], itmax=7, opts=opts)
         assert ret[i] == r and H[i, :8].tolist() == h.tolist() and info[i].tolist() == inf.tolist()
+
+
+# ---- HomographyEstimator::solve (normalised DLT) and ::residuals on the same handle (homography.cpp:17-110) ---------
+# Bar: floating point.  normalize_points and the constraint matrix are the reference's arithmetic in the reference's
+# order on both sides (the oracle's are pinned bit for bit to a numpy-float32 statement, tests/test_homography_oracle.py);
+# the null vector comes from two different, backward-stable SVDs (oracle: one-sided Jacobi on the 2N x 9 matrix, pinned
+# to LAPACK at 1e-12; device: Householder QR, then one-sided Jacobi on the triangle), so H agrees to the conditioning of
+# the smallest singular vector: DLT_TOL relative to max |H| of the problem, stated here.
+DLT_TOL = 1e-13                # measured 2e-15 over the ragged batch below
+DLT_TOL_MINIMAL = 1e-11        # four pairs: eight equations, an exact null space, no averaging of the rounding
+
+
+def _general_position_problem(rng, N):
+    """N >= 4 pairs that include the board's four corners: a few random grid points are often collinear, and a
+    degenerate set has a null space of more than one dimension (any vector of it is as good as another)"""
+    x1, y1, x2, y2, H0 = homography_problem(rng, 108)
+    corner = ((x1 == 0) | (x1 == 275)) & ((y1 == 0) | (y1 == 200))
+    idx = np.concatenate([np.flatnonzero(corner), np.flatnonzero(~corner)[:N - 4]])
+    return x1[idx], y1[idx], x2[idx], y2[idx], H0
+
+
+def _batch_of(parts):
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.int32)
+    cat = lambda k: np.concatenate([p[k] for p in parts])
+    return off, cat(0), cat(1), cat(2), cat(3), np.stack([p[4] for p in parts])
+
+
+def _dlt_oracle(orc, off, x1, y1, x2, y2, which=None):
+    out = {}
+    for i in (range(len(off) - 1) if which is None else which):
+        s = slice(off[i], off[i + 1])
+        out[i] = orc.homography_dlt(x1[s], y1[s], x2[s], y2[s])
+    return out
+
+
+def test_dlt_ragged_batch_against_oracle(orc):
+    rng = np.random.default_rng(31)
+    parts = [homography_problem(rng, int(n)) for n in np.concatenate([rng.integers(12, 200, 120), [63, 64, 65, 108, 512, 1000, 1024]])]
+    parts += [_general_position_problem(rng, n) for n in (4, 4, 5, 6, 8, 9)]
+    parts += [homography_problem(rng, n) for n in (3, 1, 2)]                # too few pairs: left alone
+    off, x1, y1, x2, y2, H0 = _batch_of(parts)
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    b.set(H0)
+    H = b.dlt()
+    worst = worst4 = 0.0
+    for i, (ret, Ho) in _dlt_oracle(orc, off, x1, y1, x2, y2).items():
+        n = off[i + 1] - off[i]
+        if n < 4:
+            assert ret == -1 and H[i].tolist() == H0[i].tolist()          # keeps its current estimate
+            continue
+        err = np.max(np.abs(H[i] - Ho)) / np.max(np.abs(Ho))
+        worst = max(worst, err if n > 4 else 0.0)
+        worst4 = max(worst4, err if n == 4 else 0.0)
+        assert err <= (DLT_TOL if n > 4 else DLT_TOL_MINIMAL), (i, n, err)
+        assert H[i, 8] == 1.0
+    print("worst relative DLT difference over the batch: %.2e (n > 4), %.2e (n = 4)" % (worst, worst4))
+    # residuals of the DLT estimates, against the oracle's on the same H
+    res = b.residuals()
+    for i in range(len(off) - 1):
+        s = slice(off[i], off[i + 1])
+        if off[i + 1] - off[i] >= 4:
+            ro = orc.homography_residuals(x1[s], y1[s], x2[s], y2[s], H[i])
+            assert np.max(np.abs(res[s] - ro)) <= 1e-11 * max(1.0, np.max(np.abs(ro)))
+
+
+def test_dlt_then_refinement_on_the_device_equals_the_reference_flow(orc):
+    """solve -> solveLM without the estimates leaving the device; the refinement from the device's DLT estimate is the
+    oracle's bit for bit (the LM is order-exact), and ends where the refinement from the oracle's DLT estimate ends"""
+    rng = np.random.default_rng(32)
+    off, x1, y1, x2, y2, _ = _batch_of([homography_problem(rng, n) for n in (108, 54, 70, 12, 200)] +
+                                       [_general_position_problem(rng, n) for n in (4, 5)])
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    Hd = b.dlt()
+    b.run()
+    H, info, ret = b.get()
+    for i in range(len(off) - 1):
+        s = slice(off[i], off[i + 1])
+        r, h, inf = orc.homography_lm(x1[s], y1[s], x2[s], y2[s], Hd[i])
+        assert ret[i] == r and H[i, :8].tolist() == h.tolist() and info[i].tolist() == inf.tolist()
+        _, Ho = orc.homography_dlt(x1[s], y1[s], x2[s], y2[s])
+        r2, h2, inf2 = orc.homography_lm(x1[s], y1[s], x2[s], y2[s], Ho)
+        assert np.max(np.abs(h2 - h)) <= 1e-7 * np.max(np.abs(h))          # two LM runs to levmar's own tolerances
+        assert abs(inf2[1] - inf[1]) <= 1e-9 * max(inf[1], 1e-12)
+        assert inf[1] <= inf[0]                                            # the refinement never loses to the DLT
+
+
+def test_residuals_with_given_estimates(orc):
+    rng = np.random.default_rng(33)
+    off, x1, y1, x2, y2, H0 = homography_batch(rng, [30, 4, 77])
+    res = HomographyBatch(off, x1, y1, x2, y2).residuals(H0)
+    for i in range(3):
+        s = slice(off[i], off[i + 1])
+        ro = orc.homography_residuals(x1[s], y1[s], x2[s], y2[s], H0[i])
+        assert np.max(np.abs(res[s] - ro)) <= 1e-11 * max(1.0, np.max(np.abs(ro)))
+
+
+def test_dlt_full_size_batch_properties_and_sampled_parity(orc):
+    """10 000 views x 108 pairs: every estimate is finite and normalised, its transfer residuals are at the noise level
+    of the synthetic pairs, a sample equals the oracle"""
+    rng = np.random.default_rng(34)
+    n = 10000
+    base = homography_batch(rng, [108] * 50)
+    rep = n // 50
+    off = (np.arange(n + 1) * 108).astype(np.int32)
+    x1, y1, x2, y2 = (np.tile(a, rep) for a in base[1:5])
+    x2 = (x2 + rng.normal(0, 0.05, x2.shape)).astype(np.float32)          # distinct problems
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    H = b.dlt()
+    assert np.all(np.isfinite(H)) and np.all(H[:, 8] == 1.0)
+    res = b.residuals().reshape(n, 108)
+    assert np.all(res.mean(axis=1) < 5.0)
+    for i, (ret, Ho) in _dlt_oracle(orc, off, x1, y1, x2, y2, which=range(0, n, 397)).items():
+        assert np.max(np.abs(H[i] - Ho)) <= DLT_TOL * np.max(np.abs(Ho)), i

@@ -71,3 +71,89 @@ def test_refinement_reaches_the_least_squares_minimum(orc):
     assert ret > 0 and info[1] < info[0] and info[6] in (1, 2, 6)
     ret2, h2, info2 = orc.homography_lm(x1, y1, x2, y2, np.append(h, 1.0))      # restart: nothing left to gain
     assert abs(info2[1] - info[1]) <= 1e-9 * info[1]
+
+
+# ---- HomographyEstimator::solve (normalised DLT) and ::residuals, homography.cpp:17-110 -----------------------------
+# PARITY UNPINNED against the reference (it holds no vectors for them, and the SVD is Eigen's); pinned here against
+# independent statements of the same arithmetic: numpy float32 for normalize_points, LAPACK's SVD for the null vector.
+
+def _normalize_np(x, y):
+    """normalize_points (homography.cpp:17-42) in numpy scalars: float32 sums in point order"""
+    f = np.float32
+    cx = f(0); cy = f(0)
+    for a, b in zip(x, y):
+        cx = f(cx + a); cy = f(cy + b)
+    n = f(len(x))
+    cx = f(cx / n); cy = f(cy / n)
+    nrm = f(0)
+    for a, b in zip(x, y):
+        dx = f(a - cx); dy = f(b - cy)
+        nrm = f(nrm + f(f(dx * dx) + f(dy * dy)))
+    nrm = f(nrm / n)
+    scale = np.sqrt(2.0) / np.float64(np.sqrt(nrm))           # np.sqrt of a float32 is the float square root
+    nx = ((x - cx).astype(np.float64) * scale).astype(np.float32)
+    ny = ((y - cy).astype(np.float64) * scale).astype(np.float32)
+    T = np.array([[scale, 0, -scale * np.float64(cx)], [0, scale, -scale * np.float64(cy)], [0, 0, 1]])
+    return nx, ny, T
+
+
+def _dlt_np(x1, y1, x2, y2):
+    a, b, T1 = _normalize_np(x1, y1)
+    c, d, T2 = _normalize_np(x2, y2)
+    u1, v1, u2, v2 = (t.astype(np.float64) for t in (a, b, c, d))
+    n = len(x1)
+    A = np.zeros((2 * n, 9))
+    A[0::2, 0] = u1; A[0::2, 1] = v1; A[0::2, 2] = 1; A[0::2, 6] = -u2 * u1; A[0::2, 7] = -u2 * v1; A[0::2, 8] = -u2
+    A[1::2, 3] = -u1; A[1::2, 4] = -v1; A[1::2, 5] = -1; A[1::2, 6] = v2 * u1; A[1::2, 7] = v2 * v1; A[1::2, 8] = v2
+    v = np.linalg.svd(A)[2][-1]
+    H = np.linalg.inv(T2) @ v.reshape(3, 3) @ T1
+    return A, T1, T2, (H / H[2, 2]).ravel()
+
+
+@pytest.mark.parametrize("N", [4, 5, 9, 54, 108, 333, 1024])
+def test_dlt_matrix_is_the_reference_arithmetic_and_the_null_vector_is_lapacks(orc, N):
+    rng = np.random.default_rng(100 + N)
+    x1, y1, x2, y2, _ = homography_problem(rng, N)
+    A, T1, T2 = orc.homography_dlt_matrix(x1, y1, x2, y2)
+    An, T1n, T2n, Hn = _dlt_np(x1, y1, x2, y2)
+    assert A.tolist() == An.tolist() and T1.tolist() == T1n.tolist() and T2.tolist() == T2n.tolist()   # bit for bit
+    ret, H = orc.homography_dlt(x1, y1, x2, y2)
+    assert 0 < ret < 60                                      # the sweeps converge
+    assert np.max(np.abs(H - Hn)) <= 1e-12 * np.max(np.abs(Hn))
+    assert H[8] == 1.0
+
+
+def test_dlt_recovers_an_exact_homography_and_its_residuals_vanish(orc):
+    rng = np.random.default_rng(12)
+    Ht = np.array([[1.1, 0.05, 30.0], [-0.04, 0.95, -12.0], [1e-4, -2e-4, 1.0]])
+    x1 = rng.uniform(0, 1280, 40).astype(np.float32); y1 = rng.uniform(0, 960, 40).astype(np.float32)
+    w = Ht[2, 0] * x1 + Ht[2, 1] * y1 + 1
+    x2 = ((Ht[0, 0] * x1 + Ht[0, 1] * y1 + Ht[0, 2]) / w).astype(np.float32)
+    y2 = ((Ht[1, 0] * x1 + Ht[1, 1] * y1 + Ht[1, 2]) / w).astype(np.float32)
+    ret, H = orc.homography_dlt(x1, y1, x2, y2)
+    assert np.max(np.abs(H - Ht.ravel()) / np.maximum(np.abs(Ht.ravel()), 1e-3)) < 1e-3      # float32 points: ~1e-7 relative on pixels
+    res = orc.homography_residuals(x1, y1, x2, y2, H)
+    assert res.shape == (40,) and np.all(res < 1e-3)
+    # the residual is the symmetric transfer error: against a direct numpy statement
+    Hm = H.reshape(3, 3); Hi = np.linalg.inv(Hm)
+    p1 = np.stack([x1, y1, np.ones(40)]).astype(np.float64); p2 = np.stack([x2, y2, np.ones(40)]).astype(np.float64)
+    f = Hm @ p1; g = Hi @ p2
+    ref = np.hypot(f[0] / f[2] - p2[0], f[1] / f[2] - p2[1]) + np.hypot(g[0] / g[2] - p1[0], g[1] / g[2] - p1[1])
+    assert np.max(np.abs(res - ref)) <= 1e-9
+
+
+def test_dlt_on_the_five_pairs_the_reference_test_lists(orc):
+    """modules/calib/test/test_homography.cpp:73,77 (commented out there): the only point data the reference holds"""
+    p1 = np.array([[1544, 592], [2236, 512], [1552, 2140], [2144, 1608], [2416, 1332]], np.float32)
+    p2 = np.array([[292, 656], [992, 596], [360, 2332], [964, 1700], [1212, 1412]], np.float32)
+    ret, H = orc.homography_dlt(p1[:, 0], p1[:, 1], p2[:, 0], p2[:, 1])
+    _, _, _, Hn = _dlt_np(p1[:, 0], p1[:, 1], p2[:, 0], p2[:, 1])
+    assert ret > 0 and np.max(np.abs(H - Hn)) <= 1e-12 * np.max(np.abs(Hn))
+    res = orc.homography_residuals(p1[:, 0], p1[:, 1], p2[:, 0], p2[:, 1], H)
+    assert np.all(res < 10.0)            # the reference's own inlier threshold for these images (test_homography.cpp:95)
+
+
+def test_dlt_with_fewer_than_four_pairs_is_refused(orc):
+    x = np.array([1, 2, 3], np.float32)
+    ret, H = orc.homography_dlt(x, x * 2, x + 1, x - 1)
+    assert ret == -1 and not H.any()
