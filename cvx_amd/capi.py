@@ -66,7 +66,7 @@ class CalibDesc(C.Structure):
     _fields_ = [("n_cameras", C.c_int), ("n_views", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int64),
                 ("cam_of_view", ip), ("view_off", ip), ("point_id", ip), ("obs_x", dp), ("obs_y", dp),
                 ("fix_k3", C.c_int), ("fix_intrinsics", C.c_int), ("fix_points", C.c_int),
-                ("device", C.c_int), ("stream", C.c_void_p)]
+                ("device", C.c_int), ("stream", C.c_void_p), ("prepare_inner_iterations", C.c_int)]
 
 
 class ToolBADesc(C.Structure):
@@ -100,6 +100,7 @@ SIGNATURES = {
     "cvx_rccl_destroy": (None, [C.c_void_p]),
     "cvx_partition_views": (C.c_int, [C.c_int, ip, C.c_int, ip]),
     "cvx_calib_create": (C.c_int, [C.POINTER(CalibDesc), C.POINTER(C.c_void_p)]),
+    "cvx_calib_prepare_inner_iterations": (C.c_int, [C.c_void_p]),
     "cvx_calib_destroy": (None, [C.c_void_p]),
     "cvx_calib_set_params": (C.c_int, [C.c_void_p, dp, dp, dp]),
     "cvx_calib_get_params": (C.c_int, [C.c_void_p, dp, dp, dp]),

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +21,19 @@
 using namespace cvxk;
 
 namespace {
+
+// CVX_CREATE_PROF=1: where cvx_calib_create / cvx_calib_destroy spend their time, on stderr (development aid)
+struct PhaseClock {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseClock() : on(std::getenv("CVX_CREATE_PROF") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[cvx prof] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 template <class Tp>
 int dev_alloc(Tp **p, size_t n) {
@@ -40,6 +54,11 @@ int dev_upload(Tp **p, const Tp *src, size_t n, hipStream_t s) {
 __global__ void k_fill(double *p, long long n, double v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+}
+
+__global__ void __launch_bounds__(64) k_view_ids(const int *__restrict__ view_off, int *__restrict__ view_id) {
+    const int v = blockIdx.x;
+    for (int o = view_off[v] + threadIdx.x; o < view_off[v + 1]; o += 64) view_id[o] = v;
 }
 
 // Jacobi scales of the shared unknowns, s_j^2 = 1 / (1 + sqrt(d_j))^2 (or 1), from the diagonal the assembly left in E:
@@ -122,6 +141,12 @@ struct cvx_calib {
     int *d_pt_view = nullptr, *d_pt_cam = nullptr;
     int pt_slices = 1;               // workgroups per point block
     double *h_ib_active = nullptr;   // pinned: [0] blocks that go on, [1..2] step norm parts
+    // the host half of the first use (ordering, the points' observation lists), possibly made ahead on a host thread
+    struct InnerHostPrep {
+        int status = CVX_OK, sets = 0;
+        std::vector<int> group, types, pt_off, pt_obs;
+    };
+    std::future<InnerHostPrep> inner_ahead;
     // exchange
     cvx_allreduce_fn xfn = nullptr;
     void *xctx = nullptr;
@@ -134,27 +159,60 @@ struct cvx_calib {
     long long ph_n[PH_COUNT] = {0, 0, 0, 0, 0, 0};
     bool ph_used[PH_COUNT] = {false, false, false, false, false, false};
 
+    // One device allocation for everything cvx_calib_create makes (a hipMalloc / hipFree pair per buffer costs ~40 us:
+    // 2 ms of a destroy, 0.3 ms of a create at 45 buffers); buffers that later calls re-size (E, X, the inner
+    // iterations' blocks, the best point, the evaluation output) stay allocations of their own.  A request the
+    // arena cannot hold falls back to hipMalloc, so its size estimate is a matter of speed, not of correctness.
+    char *arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    int arena_fallbacks = 0;
+    bool in_arena(const void *p) const { return arena && (const char *)p >= arena && (const char *)p < arena + arena_cap; }
+    template <class Tp>
+    int dalloc(Tp **p, size_t n) {
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(Tp) + 255) / 256 * 256;
+        if (arena && arena_used + bytes <= arena_cap) {
+            *p = reinterpret_cast<Tp *>(arena + arena_used);
+            arena_used += bytes;
+            return CVX_OK;
+        }
+        ++arena_fallbacks;
+        return dev_alloc(p, n);
+    }
+    template <class Tp>
+    int dupload(Tp **p, const Tp *src, size_t n, hipStream_t s) {
+        const int st = dalloc(p, n);
+        if (st) return st;
+        if (n) CVX_HIP(hipMemcpyAsync(*p, src, n * sizeof(Tp), hipMemcpyHostToDevice, s));
+        return CVX_OK;
+    }
+
     ~cvx_calib();
 };
 
 cvx_calib::~cvx_calib() {
+    if (inner_ahead.valid()) inner_ahead.wait();     // the thread reads this handle's host tables
     (void)hipSetDevice(device);
+    PhaseClock pc;
     void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_points[0], d_poses[0], d_rt[0], d_lm, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p && !in_arena(p)) (void)hipFree(p);
+    if (arena) (void)hipFree(arena);
+    pc.mark("  device frees");
     if (h_E) (void)hipHostFree(h_E);
     if (h_params) (void)hipHostFree(h_params);
     if (h_ds_emb) (void)hipHostFree(h_ds_emb);
     if (h_E2) (void)hipHostFree(h_E2);
     if (h_lm) (void)hipHostFree(h_lm);
     if (h_ib_active) (void)hipHostFree(h_ib_active);
+    pc.mark("  pinned frees");
     if (ev_made)
         for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
     if (ev_step) (void)hipEventDestroy(ev_step);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
+    pc.mark("  events, stream");
 }
 
 namespace {
@@ -422,14 +480,46 @@ __global__ void k_inner_gather(const int *__restrict__ pt_obs, const int *__rest
 // problem's graph, so the ranks first put their views' structure together -- camera, marker count and point ids of
 // every view, each rank's part at its offset of a zero buffer, one all-reduce -- and every rank orders the whole
 // problem; rank by rank the views follow each other as in the unsharded problem, so the sets are the same as there.
+// the points' observation lists: ascending observation = ascending view
+void inner_point_lists(const cvx_calib *h, std::vector<int> &pt_off, std::vector<int> &pt_obs) {
+    const std::vector<int> &point_id = h->h_point_id;
+    pt_off.assign((size_t)h->P + 1, 0); pt_obs.resize((size_t)h->N);
+    for (int64_t o = 0; o < h->N; ++o) pt_off[point_id[o] + 1]++;
+    for (int p = 0; p < h->P; ++p) pt_off[p + 1] += pt_off[p];
+    std::vector<int> pos(pt_off.begin(), pt_off.end() - 1);
+    for (int64_t o = 0; o < h->N; ++o) pt_obs[pos[point_id[o]]++] = (int)o;
+}
+
+// One-rank handles: everything of the first use that needs no device, a function of tables that do not change after
+// cvx_calib_create -- so it can run on a host thread while the caller goes on (start_inner_ahead).
+cvx_calib::InnerHostPrep inner_host_prep(const cvx_calib *h) {
+    cvx_calib::InnerHostPrep r;
+    const int C = h->C, P = h->P, V = h->V, NB = C + P + V;
+    r.group.resize(NB);
+    r.status = cvx_calib_inner_ordering(C, V, P, h->h_cam_of_view.data(), h->h_view_off.data(), h->h_point_id.data(), h->fix_intr,
+                                        h->fix_pts, r.group.data(), &r.sets);
+    if (r.status) return r;
+    r.types.assign(r.sets, 0);
+    for (int i = 0; i < NB; ++i)
+        if (r.group[i] >= 0) r.types[r.group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
+    inner_point_lists(h, r.pt_off, r.pt_obs);
+    return r;
+}
+
+void start_inner_ahead(cvx_calib *h) {
+    if (h->inner_ready || h->inner_ahead.valid() || h->nranks > 1) return;
+    h->inner_ahead = std::async(std::launch::async, inner_host_prep, (const cvx_calib *)h);
+}
+
 int ensure_inner(cvx_calib *h) {
     if (h->inner_ready) return CVX_OK;
     free_inner(h);
     const int C = h->C, P = h->P, V = h->V, NB = C + P + V;
     const std::vector<int> &point_id = h->h_point_id;
-    std::vector<int> group(NB);
+    std::vector<int> group(NB), pt_off, pt_obs;
     int st;
     if (h->nranks > 1) {
+        if (h->inner_ahead.valid()) (void)h->inner_ahead.get();      // made for the unsharded problem: of no use now
         const int R = h->nranks;
         std::vector<double> cnt(2 * (size_t)R, 0.0);
         cnt[2 * h->rank] = V; cnt[2 * h->rank + 1] = (double)h->N;
@@ -461,20 +551,12 @@ int ensure_inner(cvx_calib *h) {
             if (ggroup[i] >= 0) h->inner_types[ggroup[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
         for (int i = 0; i < C + P; ++i) group[i] = ggroup[i];
         for (int v = 0; v < V; ++v) group[C + P + v] = ggroup[(size_t)(C + P + v0 + v)];
+        inner_point_lists(h, pt_off, pt_obs);
     } else {
-        st = cvx_calib_inner_ordering(C, V, P, h->h_cam_of_view.data(), h->h_view_off.data(), point_id.data(), h->fix_intr,
-                                      h->fix_pts, group.data(), &h->inner_sets);
-        if (st) return st;
-        h->inner_types.assign(h->inner_sets, 0);
-        for (int i = 0; i < NB; ++i)
-            if (group[i] >= 0) h->inner_types[group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
-    }
-    std::vector<int> pt_off((size_t)P + 1, 0), pt_obs((size_t)h->N);
-    for (int64_t o = 0; o < h->N; ++o) pt_off[point_id[o] + 1]++;
-    for (int p = 0; p < P; ++p) pt_off[p + 1] += pt_off[p];
-    {
-        std::vector<int> pos(pt_off.begin(), pt_off.end() - 1);
-        for (int64_t o = 0; o < h->N; ++o) pt_obs[pos[point_id[o]]++] = (int)o;      // ascending observation = ascending view
+        cvx_calib::InnerHostPrep r = h->inner_ahead.valid() ? h->inner_ahead.get() : inner_host_prep(h);
+        if (r.status) return r.status;
+        h->inner_sets = r.sets;
+        h->inner_types.swap(r.types); group.swap(r.group); pt_off.swap(r.pt_off); pt_obs.swap(r.pt_obs);
     }
     hipStream_t s = h->stream;
     // a point's list is cut so that a workgroup of 256 lanes sees about two observations per lane
@@ -971,6 +1053,7 @@ int alloc_exchange(cvx_calib *h) {
 extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     if (!d || !out) return CVX_ERR_INVALID_ARG;
     *out = nullptr;
+    PhaseClock pc;
     if (d->n_cameras < 1 || d->n_cameras > CVX_MAX_CAMERAS || d->n_views < 0 || d->n_points < 1 || d->n_obs < 0)
         return CVX_ERR_INVALID_ARG;
     if (!d->cam_of_view || !d->view_off || (d->n_obs > 0 && (!d->point_id || !d->obs_x || !d->obs_y)))
@@ -1003,6 +1086,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     if (d->device < 0 || d->device >= ndev) return CVX_ERR_NO_DEVICE;
     CVX_HIP(hipSetDevice(d->device));
 
+    pc.mark("validation");
     cvx_calib *h = new cvx_calib;
     std::unique_ptr<cvx_calib> guard(h);
     h->C = C; h->V = V; h->P = P; h->N = d->n_obs;
@@ -1036,6 +1120,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     h->h_cam_of_view.assign(d->cam_of_view, d->cam_of_view + V);
     h->h_view_off.assign(d->view_off, d->view_off + V + 1);
     if (d->n_obs) h->h_point_id.assign(d->point_id, d->point_id + d->n_obs);
+    if (d->prepare_inner_iterations) start_inner_ahead(h);      // beside the rest of this function
 
     // groups (K2 workgroups) and chunks (K3 row ranges): contiguous views of one camera
     std::vector<int> grp_v0, grp_cam, chk_row0, chk_cam;
@@ -1083,77 +1168,94 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         std::vector<int> pos(glist_off.begin(), glist_off.end() - 1);
         for (int g = 0; g < h->n_groups; ++g) glist[pos[grp_cam[g]]++] = g;
     }
-    std::vector<int> view_id((size_t)h->N);
-    for (int v = 0; v < V; ++v)
-        for (int o = d->view_off[v]; o < d->view_off[v + 1]; ++o) view_id[o] = v;
-
     hipStream_t s = h->stream;
     int st;
+    pc.mark("host tables");
 #define CVX_TRY(x) do { st = (x); if (st) return st; } while (0)
-    CVX_TRY(dev_upload(&h->d_view_off, d->view_off, (size_t)V + 1, s));
-    CVX_TRY(dev_upload(&h->d_cam_of_view, d->cam_of_view, (size_t)V, s));
-    CVX_TRY(dev_upload(&h->d_point_id, d->point_id, (size_t)h->N, s));
-    CVX_TRY(dev_upload(&h->d_view_id, view_id.data(), (size_t)h->N, s));
-    CVX_TRY(dev_upload(&h->d_obs_x, d->obs_x, (size_t)h->N, s));
-    CVX_TRY(dev_upload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
-    CVX_TRY(dev_upload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
-    CVX_TRY(dev_upload(&h->d_chk_row0, chk_row0.data(), chk_row0.size(), s));
-    if (!k4tasks.empty()) CVX_TRY(dev_upload(&h->d_k4tasks, k4tasks.data(), k4tasks.size(), s));
+    {
+        // the arena: the sum of what follows, each buffer rounded up to 256 bytes (dalloc), plus slack
+        auto up32 = [](size_t n) { return (std::max<size_t>(n, 1) + 31) / 32 * 32; };
+        const size_t Nn = (size_t)h->N, Vn = (size_t)V, G = (size_t)h->n_groups, Q = (size_t)h->n_chunks;
+        const size_t npad_ = (size_t)((h->ns + 1 + cvxs::TB - 1) / cvxs::TB) * cvxs::TB;
+        const size_t ints = (Vn + 1) + Vn + 2 * Nn + (G + 1) + (Q + 1) + Q + G + 2 * ((size_t)C + 1) + 1;
+        const size_t doubles = 2 * Nn + 2 * (up32(9 * (size_t)C) + up32(3 * (size_t)P) + up32(6 * Vn) + up32(Vn * RT_STRIDE)) +
+                               (6 * Vn + 8) * h->ZC + (21 + 6 * 3 + 6 + 3 + 1) * Vn + G * P * PT_ACC + G * 256 + G * 4 +
+                               Q * h->nblk * 256 + (size_t)C * P * PT_ACC + (size_t)C * h->nblk * 256 + (size_t)C * 256 +
+                               (size_t)C * h->ZC + 2048 + 16 + 2 * npad_ * npad_ + 3 * (size_t)std::max(1, h->ns);
+        h->arena_cap = ints * sizeof(int) + doubles * sizeof(double) + k4tasks.size() * sizeof(K4Task) + sizeof(LmDev) + 64 * 256 + 65536;
+        if (hipMalloc((void **)&h->arena, h->arena_cap) != hipSuccess) {     // no arena: every buffer on its own
+            (void)hipGetLastError();
+            h->arena = nullptr; h->arena_cap = 0;
+        }
+    }
+    CVX_TRY(h->dupload(&h->d_view_off, d->view_off, (size_t)V + 1, s));
+    CVX_TRY(h->dupload(&h->d_cam_of_view, d->cam_of_view, (size_t)V, s));
+    CVX_TRY(h->dupload(&h->d_point_id, d->point_id, (size_t)h->N, s));
+    CVX_TRY(h->dalloc(&h->d_view_id, (size_t)h->N));       // every observation's view: made on the device from the offsets
+    if (V) hipLaunchKernelGGL(k_view_ids, dim3((unsigned)V), dim3(64), 0, s, h->d_view_off, h->d_view_id);
+    CVX_TRY(h->dupload(&h->d_obs_x, d->obs_x, (size_t)h->N, s));
+    CVX_TRY(h->dupload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
+    CVX_TRY(h->dupload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
+    CVX_TRY(h->dupload(&h->d_chk_row0, chk_row0.data(), chk_row0.size(), s));
+    if (!k4tasks.empty()) CVX_TRY(h->dupload(&h->d_k4tasks, k4tasks.data(), k4tasks.size(), s));
     {
         std::vector<int> clist(h->n_chunks), clist_off(C + 1, 0);
         for (int q = 0; q < h->n_chunks; ++q) clist_off[chk_cam[q] + 1]++;
         for (int c = 0; c < C; ++c) clist_off[c + 1] += clist_off[c];
         std::vector<int> pos(clist_off.begin(), clist_off.end() - 1);
         for (int q = 0; q < h->n_chunks; ++q) clist[pos[chk_cam[q]]++] = q;
-        CVX_TRY(dev_upload(&h->d_clist, clist.data(), clist.size(), s));
-        CVX_TRY(dev_upload(&h->d_clist_off, clist_off.data(), clist_off.size(), s));
+        CVX_TRY(h->dupload(&h->d_clist, clist.data(), clist.size(), s));
+        CVX_TRY(h->dupload(&h->d_clist_off, clist_off.data(), clist_off.size(), s));
     }
-    CVX_TRY(dev_upload(&h->d_glist, glist.data(), glist.size(), s));
-    CVX_TRY(dev_upload(&h->d_glist_off, glist_off.data(), glist_off.size(), s));
+    CVX_TRY(h->dupload(&h->d_glist, glist.data(), glist.size(), s));
+    CVX_TRY(h->dupload(&h->d_glist_off, glist_off.data(), glist_off.size(), s));
+    pc.mark("uploads");
     {
         auto up32 = [](size_t n) { return (long long)((std::max<size_t>(n, 1) + 31) / 32 * 32); };
         h->intr_step = up32(9 * (size_t)C); h->points_step = up32(3 * (size_t)P);
         h->poses_step = up32(6 * (size_t)V); h->rt_step = up32((size_t)V * RT_STRIDE);
-        CVX_TRY(dev_alloc(&h->d_intr[0], 2 * (size_t)h->intr_step));
-        CVX_TRY(dev_alloc(&h->d_points[0], 2 * (size_t)h->points_step));
-        CVX_TRY(dev_alloc(&h->d_poses[0], 2 * (size_t)h->poses_step));
-        CVX_TRY(dev_alloc(&h->d_rt[0], 2 * (size_t)h->rt_step));
+        CVX_TRY(h->dalloc(&h->d_intr[0], 2 * (size_t)h->intr_step));
+        CVX_TRY(h->dalloc(&h->d_points[0], 2 * (size_t)h->points_step));
+        CVX_TRY(h->dalloc(&h->d_poses[0], 2 * (size_t)h->poses_step));
+        CVX_TRY(h->dalloc(&h->d_rt[0], 2 * (size_t)h->rt_step));
         h->d_intr[1] = h->d_intr[0] + h->intr_step; h->d_points[1] = h->d_points[0] + h->points_step;
         h->d_poses[1] = h->d_poses[0] + h->poses_step; h->d_rt[1] = h->d_rt[0] + h->rt_step;
         CVX_HIP(hipMemsetAsync(h->d_intr[0], 0, 2 * (size_t)h->intr_step * sizeof(double), s));
         CVX_HIP(hipMemsetAsync(h->d_points[0], 0, 2 * (size_t)h->points_step * sizeof(double), s));
         CVX_HIP(hipMemsetAsync(h->d_poses[0], 0, 2 * (size_t)h->poses_step * sizeof(double), s));
-        CVX_TRY(dev_alloc(&h->d_lm, 1));
+        CVX_TRY(h->dalloc(&h->d_lm, 1));
         CVX_HIP(hipMemsetAsync(h->d_lm, 0, sizeof(LmDev), s));
         CVX_HIP(hipHostMalloc((void **)&h->h_lm, sizeof(LmDev), hipHostMallocDefault));
     }
     const size_t zn = ((size_t)6 * V + 8) * h->ZC;
-    CVX_TRY(dev_alloc(&h->d_Z, zn));
+    CVX_TRY(h->dalloc(&h->d_Z, zn));
     CVX_HIP(hipMemsetAsync(h->d_Z, 0, zn * sizeof(double), s));
-    CVX_TRY(dev_alloc(&h->d_Linv, 21 * (size_t)V));
-    CVX_TRY(dev_alloc(&h->d_Dv, 6 * (size_t)V));
-    CVX_TRY(dev_alloc(&h->d_gv, 6 * (size_t)V));
-    CVX_TRY(dev_alloc(&h->d_s2pose, 6 * (size_t)V));
+    CVX_TRY(h->dalloc(&h->d_Linv, 21 * (size_t)V));
+    CVX_TRY(h->dalloc(&h->d_Dv, 6 * (size_t)V));
+    CVX_TRY(h->dalloc(&h->d_gv, 6 * (size_t)V));
+    CVX_TRY(h->dalloc(&h->d_s2pose, 6 * (size_t)V));
     if (V) hipLaunchKernelGGL(k_fill, dim3((unsigned)((6LL * V + 255) / 256)), dim3(256), 0, s, h->d_s2pose, 6LL * V, 1.0);
-    CVX_TRY(dev_alloc(&h->d_slab_pt, (size_t)h->n_groups * P * PT_ACC));
+    CVX_TRY(h->dalloc(&h->d_slab_pt, (size_t)h->n_groups * P * PT_ACC));
     CVX_HIP(hipMemsetAsync(h->d_slab_pt, 0, std::max<size_t>(1, (size_t)h->n_groups * P * PT_ACC) * sizeof(double), s));
-    CVX_TRY(dev_alloc(&h->d_slab_cam, (size_t)h->n_groups * 256));
-    CVX_TRY(dev_alloc(&h->d_grp_scal, (size_t)h->n_groups * 4));
-    CVX_TRY(dev_alloc(&h->d_slab_tile, (size_t)h->n_chunks * h->nblk * 256));
-    CVX_TRY(dev_alloc(&h->d_Tpt, (size_t)C * P * PT_ACC));
+    CVX_TRY(h->dalloc(&h->d_slab_cam, (size_t)h->n_groups * 256));
+    CVX_TRY(h->dalloc(&h->d_grp_scal, (size_t)h->n_groups * 4));
+    CVX_TRY(h->dalloc(&h->d_slab_tile, (size_t)h->n_chunks * h->nblk * 256));
+    CVX_TRY(h->dalloc(&h->d_Tpt, (size_t)C * P * PT_ACC));
     CVX_HIP(hipMemsetAsync(h->d_Tpt, 0, (size_t)C * P * PT_ACC * sizeof(double), s));
-    CVX_TRY(dev_alloc(&h->d_Tt, (size_t)C * h->nblk * 256));
-    CVX_TRY(dev_alloc(&h->d_Gcam, (size_t)C * 256));
+    CVX_TRY(h->dalloc(&h->d_Tt, (size_t)C * h->nblk * 256));
+    CVX_TRY(h->dalloc(&h->d_Gcam, (size_t)C * 256));
+    pc.mark("allocations 1");
     CVX_TRY(alloc_exchange(h));
-    CVX_TRY(dev_alloc(&h->d_ds_emb, (size_t)C * h->ZC));
+    pc.mark("alloc_exchange");
+    CVX_TRY(h->dalloc(&h->d_ds_emb, (size_t)C * h->ZC));
     CVX_HIP(hipHostMalloc((void **)&h->h_ds_emb, sizeof(double) * (size_t)C * h->ZC, hipHostMallocDefault));
-    CVX_TRY(dev_alloc(&h->d_dposes, 6 * (size_t)V));
-    CVX_TRY(dev_alloc(&h->d_out_view, 3 * (size_t)V));
+    CVX_TRY(h->dalloc(&h->d_dposes, 6 * (size_t)V));
+    CVX_TRY(h->dalloc(&h->d_out_view, 3 * (size_t)V));
     h->n_cost_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (h->N + 255) / 256));
-    CVX_TRY(dev_alloc(&h->d_cost_partial, (size_t)h->n_cost_blocks));
-    CVX_TRY(dev_alloc(&h->d_cost_view, (size_t)std::max(h->V, 1)));
+    CVX_TRY(h->dalloc(&h->d_cost_partial, (size_t)h->n_cost_blocks));
+    CVX_TRY(h->dalloc(&h->d_cost_view, (size_t)std::max(h->V, 1)));
     CVX_HIP(hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
-    CVX_TRY(dev_alloc(&h->d_E2, 16));
+    CVX_TRY(h->dalloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
     // two records of 32 doubles (a speculated step may publish while the host still reads the one before)
     CVX_HIP(hipHostMalloc((void **)&h->h_E2, 64 * sizeof(double), hipHostMallocMapped));
@@ -1163,12 +1265,12 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     h->nT = (h->ns + 1 + cvxs::TB - 1) / cvxs::TB;
     h->npad = h->nT * cvxs::TB;
     // + npad extra rows below: the identity block whose elimination yields the solution (k_chol_step); never initialised
-    CVX_TRY(dev_alloc(&h->d_A, 2 * (size_t)h->npad * h->npad));
-    CVX_TRY(dev_alloc(&h->d_s2sh, (size_t)std::max(1, h->ns)));
-    CVX_TRY(dev_alloc(&h->d_Ds, (size_t)std::max(1, h->ns)));
+    CVX_TRY(h->dalloc(&h->d_A, 2 * (size_t)h->npad * h->npad));
+    CVX_TRY(h->dalloc(&h->d_s2sh, (size_t)std::max(1, h->ns)));
+    CVX_TRY(h->dalloc(&h->d_Ds, (size_t)std::max(1, h->ns)));
     CVX_HIP(hipMemsetAsync(h->d_Ds, 0, (size_t)std::max(1, h->ns) * sizeof(double), s));
-    CVX_TRY(dev_alloc(&h->d_delta_s, (size_t)std::max(1, h->ns)));
-    CVX_TRY(dev_alloc(&h->d_fail, 1));
+    CVX_TRY(h->dalloc(&h->d_delta_s, (size_t)std::max(1, h->ns)));
+    CVX_TRY(h->dalloc(&h->d_fail, 1));
     h->fin_lds = sizeof(double) * cvxs::finish_lds_doubles(h->ns);
 #undef CVX_TRY
     hipLaunchKernelGGL(k_fill, dim3((std::max(1, h->ns) + 255) / 256), dim3(256), 0, s, h->d_s2sh, (long long)std::max(1, h->ns), 1.0);
@@ -1179,12 +1281,19 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         CVX_HIP(hipEventCreate(&h->ev[i][1]));
     }
     h->ev_made = true;
+    pc.mark("allocations 2, events");
+    if (pc.on) std::fprintf(stderr, "[cvx prof] arena: %.1f of %.1f MB used, %d buffers outside it\n", h->arena_used / 1048576.0, h->arena_cap / 1048576.0, h->arena_fallbacks);
     CVX_HIP(hipStreamSynchronize(s));
+    pc.mark("stream synchronize");
     *out = guard.release();
     return CVX_OK;
 }
 
-extern "C" void cvx_calib_destroy(cvx_calib *h) { delete h; }
+extern "C" void cvx_calib_destroy(cvx_calib *h) {
+    PhaseClock pc;
+    delete h;
+    pc.mark("destroy");
+}
 
 extern "C" int cvx_calib_set_params(cvx_calib *h, const double *intr, const double *poses, const double *points) {
     if (!h || !intr || !points || (h->V > 0 && !poses)) return CVX_ERR_INVALID_ARG;
@@ -1364,8 +1473,16 @@ extern "C" int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *c
 extern "C" int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *summary) {
     if (!h || !opt || !summary) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
+    // the host half of the inner iterations' first use runs beside the initial linearisation and the first step
+    if (opt->inner_iterations && opt->strategy == 0) start_inner_ahead(h);
     CalibEvaluator ev(h);
     return cvx::lm_minimize(ev, *opt, *summary);
+}
+
+extern "C" int cvx_calib_prepare_inner_iterations(cvx_calib *h) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    start_inner_ahead(h);
+    return CVX_OK;
 }
 
 extern "C" double cvx_calib_refine_return(double total_cost, int64_t n_obs_total) {

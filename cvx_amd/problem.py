@@ -13,7 +13,7 @@ class Calib:
     (/root/reference/modules/calib/src/calibration.cpp:354-464) on one GPU."""
 
     def __init__(self, cam_of_view, view_off, point_id, obs_x, obs_y, n_cameras, n_points,
-                 fix_k3=True, fix_intrinsics=False, fix_points=False, device=0, stream=None):
+                 fix_k3=True, fix_intrinsics=False, fix_points=False, device=0, stream=None, prepare_inner=False):
         self.cam_of_view = i32(cam_of_view); self.view_off = i32(view_off); self.point_id = i32(point_id)
         self.obs_x = f64(obs_x); self.obs_y = f64(obs_y)
         self.C, self.P = int(n_cameras), int(n_points)
@@ -21,7 +21,7 @@ class Calib:
         d = capi.CalibDesc(self.C, self.V, self.P, self.N, pi(self.cam_of_view), pi(self.view_off),
                            pi(self.point_id), pd(self.obs_x), pd(self.obs_y),
                            int(fix_k3), int(fix_intrinsics), int(fix_points), int(device),
-                           C.c_void_p(stream) if stream else None)
+                           C.c_void_p(stream) if stream else None, int(prepare_inner))
         self.h = C.c_void_p()
         check(lib().cvx_calib_create(C.byref(d), C.byref(self.h)), "cvx_calib_create")
         self.ns = lib().cvx_calib_num_shared(self.h)
@@ -42,6 +42,9 @@ class Calib:
         intr, poses, points = f64(intr), f64(poses), f64(points)
         assert intr.size == 9 * self.C and poses.size == 6 * self.V and points.size == 3 * self.P
         check(lib().cvx_calib_set_params(self.h, pd(intr), pd(poses), pd(points)), "set_params")
+
+    def prepare_inner_iterations(self):
+        check(lib().cvx_calib_prepare_inner_iterations(self.h), "prepare_inner_iterations")
 
     def get_params(self):
         intr = np.zeros((self.C, 9)); poses = np.zeros((self.V, 6)); points = np.zeros((self.P, 3))

@@ -132,6 +132,10 @@ typedef struct {
     int fix_points;           /* 0 in the reference (board points are free blocks, calibration.cpp:397) */
     int device;               /* HIP device ordinal */
     void *stream;             /* hipStream_t to run on, or NULL: the handle creates its own */
+    int prepare_inner_iterations; /* 1: the host half of the inner iterations' first use (Ceres' ordering of the blocks
+                               * into independent sets, the points' observation lists: ~2 ms at 1 M observations) starts
+                               * on a host thread inside cvx_calib_create, beside its uploads -- for callers that go on
+                               * to solve with the reference's options (use_inner_iterations, calibration.cpp:424) */
 } cvx_calib_desc;
 
 /* limits of this build (cvx_calib_create returns CVX_ERR_UNSUPPORTED beyond them).  A view lists a board point
@@ -142,6 +146,10 @@ typedef struct {
 #define CVX_MAX_CAMERAS 64
 
 int cvx_calib_create(const cvx_calib_desc *desc, cvx_calib **out);
+/* the same preparation for a handle made without the flag: starts it on a host thread and returns at once (a no-op when
+ * it is under way or done, and on view-sharded handles, whose first use is a collective).  cvx_calib_solve starts it
+ * itself when its options ask for inner iterations, beside the initial linearisation. */
+int cvx_calib_prepare_inner_iterations(cvx_calib *h);
 void cvx_calib_destroy(cvx_calib *h);
 
 /* parameter blocks in the reference's layouts: intrinsics[n_cameras][9] in the order

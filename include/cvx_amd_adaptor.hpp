@@ -117,6 +117,7 @@ double refine(const Data &data, Camera &cam, std::vector<Mat4> &extrinsics, bool
     d.obs_x = ox.data(); d.obs_y = oy.data();
     d.fix_k3 = 1; d.fix_intrinsics = intrinsics ? 0 : 1; d.fix_points = 0;
     d.device = device; d.stream = stream;
+    d.prepare_inner_iterations = 1;                 // the solve below runs with use_inner_iterations (calibration.cpp:424)
     cvx_calib *h = nullptr;
     check(cvx_calib_create(&d, &h), "cvx_calib_create");
     struct Guard { cvx_calib *h; ~Guard() { cvx_calib_destroy(h); } } guard{h};

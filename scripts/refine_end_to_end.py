@@ -1,0 +1,28 @@
+"""What one drop-in refine() call costs end to end at config 4 (development aid): handle creation (allocations, upload
+of the observations), parameter upload, the solve with the reference's options (first use of the inner iterations
+included), download, destruction."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cvx_amd  # noqa: E402
+from cvx_amd import capi  # noqa: E402
+
+d = cvx_amd.synth_calib(8, 1250, 12, 9, 20260004)
+x = (d["intr_init"], d["poses_init"], d["points_init"])
+for rep in range(6):
+    ahead = rep >= 3        # the adaptor's way: the inner iterations' host preparation starts inside create
+    t0 = time.perf_counter()
+    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 8, 108, prepare_inner=ahead)
+    t1 = time.perf_counter()
+    g.set_params(*x)
+    t2 = time.perf_counter()
+    s = g.solve(capi.options("refine"))
+    t3 = time.perf_counter()
+    g.get_params()
+    t4 = time.perf_counter()
+    g.close()
+    t5 = time.perf_counter()
+    print(("ahead  " if ahead else "on use ") + "create %.2f | set %.2f | solve %.2f (%d iterations) | get %.2f | destroy %.2f | total %.2f ms" % (
+        1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), s.iterations, 1e3 * (t4 - t3), 1e3 * (t5 - t4), 1e3 * (t5 - t0)))

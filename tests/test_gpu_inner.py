@@ -189,3 +189,28 @@ def test_config4_size_passes(orc):
     rms = capi.lib().cvx_calib_refine_return(s.final_cost, d["N"])
     assert abs(rms - 0.5 * np.sqrt(2) * 0.1) < 0.02 * 0.0707
     g.close()
+
+
+def test_first_use_prepared_ahead_gives_the_same_solve():
+    """cvx_calib_desc.prepare_inner_iterations / cvx_calib_prepare_inner_iterations: the host half of the first use
+    on a host thread changes when it is made, not what it is -- summary, trace and parameters bit for bit; and a handle
+    can be destroyed while that thread is still at work"""
+    d = cvx_amd.synth_calib(2, 150, 12, 9, 77, ragged=3)
+    args = (d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 2, 108)
+    runs = []
+    for mode in ("on use", "flag", "call"):
+        g = cvx_amd.Calib(*args, prepare_inner=(mode == "flag"))
+        if mode == "call":
+            g.prepare_inner_iterations()
+            g.prepare_inner_iterations()                # a second call is a no-op
+        g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+        s = g.solve(capi.options("refine"))
+        runs.append((s.iterations, s.termination, s.num_inner_iteration_steps, s.final_cost, s.trace()["cost"].tolist(),
+                     [a.tolist() for a in g.get_params()]))
+        g.close()
+    assert runs[0][2] >= 1                              # the passes did run
+    assert runs[1] == runs[0] and runs[2] == runs[0]
+    for _ in range(3):                                  # destroyed at once: the destructor waits for the thread
+        cvx_amd.Calib(*args, prepare_inner=True).close()
+    big = cvx_amd.synth_calib(8, 1250, 12, 9, 20260004)
+    cvx_amd.Calib(big["cam_of_view"], big["view_off"], big["point_id"], big["obs_x"], big["obs_y"], 8, 108, prepare_inner=True).close()
