@@ -502,6 +502,27 @@ def main():
                      "observation_iterations_per_s_whole_refine_with": d["N"] * fs.iterations / (full["ms_total"] * 1e-3),
                      "observation_iterations_per_s_whole_refine_without": d["N"] * fs0.iterations / (ms0 * 1e-3)}
 
+        # ---- what one drop-in refine() costs end to end: a handle's whole life around the solve above ----
+        end_to_end = None
+        if world == 1:
+            for _ in range(2):
+                tl = [time.perf_counter()]
+                g2 = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], CAMERAS,
+                                   BOARD_W * BOARD_H, device=local_rank, prepare_inner=True)
+                tl.append(time.perf_counter())
+                g2.set_params(intr0, d["poses_init"], pts0)
+                fs2 = g2.solve(capi.options("refine"))
+                tl.append(time.perf_counter())
+                g2.get_params()
+                g2.close()
+                tl.append(time.perf_counter())
+            end_to_end = {"create_ms": 1e3 * (tl[1] - tl[0]), "set_and_solve_ms": 1e3 * (tl[2] - tl[1]),
+                          "get_and_destroy_ms": 1e3 * (tl[3] - tl[2]), "total_ms": 1e3 * (tl[3] - tl[0]),
+                          "iterations": fs2.iterations, "inner_iteration_steps": fs2.num_inner_iteration_steps,
+                          "note": "cvx_calib_create (26 MB of observations uploaded from pageable memory) -> set_params -> "
+                                  "cvx_calib_solve with the reference's options, first use of the inner iterations included "
+                                  "(its host half prepared on a host thread from inside create) -> get_params -> destroy"}
+
         # ---- evaluation mode: residuals + Jacobian blocks materialised in HBM (k_eval), hipEvent-timed ----
         g.set_params(intr0, d["poses_init"], pts0)
         g.evaluate_device()
@@ -588,6 +609,14 @@ def main():
                                                                  "iterations": hs.iterations, "accepted": hs.num_successful,
                                                                  "termination": hs.termination}
             he.close()
+            # a handle's whole life, as the adaptor's solveNonLinear runs it: create (upload of the pairs), solve, destroy
+            for _ in range(2):
+                th = time.perf_counter()
+                he2 = cvx_amd.HandEye(*q, device=local_rank)
+                he2.solve(x0, hd)
+                he2.close()
+                life = 1e3 * (time.perf_counter() - th)
+            handeye[name]["solve_with_the_reference_options"]["ms_create_solve_destroy"] = life
             if world == 1 and not a.no_cpu_baseline:
                 handeye[name]["cpu_baseline"] = handeye_cpu_baseline(q, x0, 20 if moving else 5)
 
@@ -720,6 +749,8 @@ def main():
         out["inner_iterations"] = inner
         out["handeye"] = handeye
         out["homography"] = homography
+        if end_to_end is not None:
+            out["refine_end_to_end"] = end_to_end
         out["tool_bundle_adjustment"] = toolba
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_views, a.cpu_iters)

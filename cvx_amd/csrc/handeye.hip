@@ -28,18 +28,18 @@ struct cvx_handeye {
     double *h_out = nullptr, *h_p7 = nullptr;
     double *d_eval = nullptr;
     long long lm_seq = 0;
-    HeLmOut *d_lm = nullptr, *h_lm = nullptr;    // result of the one-launch solve (k_he_lm): host-mapped, made on first use
+    HeLmOut *d_lm = nullptr, *h_lm = nullptr;    // result of the one-launch solve (k_he_lm): host-mapped, inside the pinned block
     // exchange
     cvx_allreduce_fn xfn = nullptr;
     void *xctx = nullptr;
     int rank = 0, nranks = 1, xdev = 0;
     ~cvx_handeye() {
         (void)hipSetDevice(device);
-        for (void *p : {(void *)d_pairs, (void *)d_p7, (void *)d_partial, (void *)d_out, (void *)d_eval})
+        // d_pairs heads the handle's one device block (p7, partial sums and outputs behind it), h_out its one pinned
+        // block (h_p7 and the one-launch solve's record behind it)
+        for (void *p : {(void *)d_pairs, (void *)d_eval})
             if (p) (void)hipFree(p);
         if (h_out) (void)hipHostFree(h_out);
-        if (h_p7) (void)hipHostFree(h_p7);
-        if (h_lm) (void)hipHostFree(h_lm);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -119,10 +119,9 @@ int device_normal_eq(cvx_handeye *h, const double p[7], double H[36], double g[6
 int device_lm(cvx_handeye *h, double p[7], const cvx_lm_options &opt, cvx_lm_summary &sum) {
     const auto t0 = std::chrono::steady_clock::now();
     std::memset(&sum, 0, sizeof sum);
-    if (!h->h_lm) {
-        // the kernel writes its result straight into pinned host memory (posted writes, 33 KB at most): one
-        // synchronisation and no copy between the launch and the answer
-        CVX_HIP(hipHostMalloc((void **)&h->h_lm, sizeof(HeLmOut), hipHostMallocMapped));
+    // the kernel writes its result straight into pinned host memory (posted writes, 33 KB at most): one
+    // synchronisation and no copy between the launch and the answer
+    if (!h->d_lm) {
         CVX_HIP(hipHostGetDevicePointer((void **)&h->d_lm, h->h_lm, 0));
         h->h_lm->seq = 0;
     }
@@ -306,13 +305,15 @@ extern "C" int cvx_handeye_create(int n_pairs, const double *qa, const double *t
         for (int k = 0; k < 4; ++k) { planes[k * n + i] = qa[4 * i + k]; planes[(7 + k) * n + i] = qb[4 * i + k]; }
         for (int k = 0; k < 3; ++k) { planes[(4 + k) * n + i] = ta[3 * i + k]; planes[(11 + k) * n + i] = tb[3 * i + k]; }
     }
-    CVX_HIP(hipMalloc((void **)&h->d_pairs, planes.size() * sizeof(double)));
+    // one device block and one pinned block per handle (an allocation costs more than a small solve's iteration)
+    auto up32 = [](size_t c) { return (c + 31) / 32 * 32; };
+    const size_t o_p7 = up32(planes.size()), o_partial = o_p7 + 32, o_out = o_partial + up32((size_t)h->n_blocks * HE_ACC);
+    CVX_HIP(hipMalloc((void **)&h->d_pairs, (o_out + 32) * sizeof(double)));
+    h->d_p7 = h->d_pairs + o_p7; h->d_partial = h->d_pairs + o_partial; h->d_out = h->d_pairs + o_out;
     CVX_HIP(hipMemcpyAsync(h->d_pairs, planes.data(), planes.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    CVX_HIP(hipMalloc((void **)&h->d_p7, 8 * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_partial, (size_t)h->n_blocks * HE_ACC * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_out, 32 * sizeof(double)));
-    CVX_HIP(hipHostMalloc((void **)&h->h_out, 32 * sizeof(double), hipHostMallocDefault));
-    CVX_HIP(hipHostMalloc((void **)&h->h_p7, 8 * sizeof(double), hipHostMallocDefault));
+    CVX_HIP(hipHostMalloc((void **)&h->h_out, 64 * sizeof(double) + sizeof(HeLmOut), hipHostMallocMapped));
+    h->h_p7 = h->h_out + 32;
+    h->h_lm = reinterpret_cast<HeLmOut *>(h->h_out + 64);
     CVX_HIP(hipStreamSynchronize(h->stream));
     *out = guard.release();
     return CVX_OK;
