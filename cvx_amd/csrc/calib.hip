@@ -61,6 +61,34 @@ __global__ void __launch_bounds__(64) k_view_ids(const int *__restrict__ view_of
     for (int o = view_off[v] + threadIdx.x; o < view_off[v + 1]; o += 64) view_id[o] = v;
 }
 
+// cvx_calib_create's checks of the observation lists, on the device (a host pass over 1 M observations costs 0.3 ms of
+// a 1.5 ms create).  flags[0]: a point id out of range; flags[1]: a view lists a point twice.  One block per view.
+__global__ void __launch_bounds__(64) k_check_views(const int *__restrict__ view_off, const int *__restrict__ point_id, int P,
+                                                     int *__restrict__ flags) {
+    __shared__ unsigned seen[(CVX_MAX_POINTS + 31) / 32];
+    const int v = blockIdx.x;
+    if (threadIdx.x < (CVX_MAX_POINTS + 31) / 32) seen[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int o = view_off[v] + threadIdx.x; o < view_off[v + 1]; o += 64) {
+        const int pid = point_id[o];
+        if (pid < 0 || pid >= P) { flags[0] = 1; continue; }
+        const unsigned bit = 1u << (pid & 31);
+        if (atomicOr(&seen[pid >> 5], bit) & bit) flags[1] = 1;
+    }
+}
+// flags[2]: some group's views do not all list the same points in the same order.  One block per group of views.
+__global__ void __launch_bounds__(128) k_check_aligned(const int *__restrict__ view_off, const int *__restrict__ point_id,
+                                                        const int *__restrict__ grp_v0, int *__restrict__ flags) {
+    const int g = blockIdx.x, a0 = grp_v0[g], a1 = grp_v0[g + 1];
+    const int o0 = view_off[a0], n0 = view_off[a0 + 1] - o0;
+    for (int v = a0 + 1; v < a1; ++v) {
+        const int o = view_off[v];
+        if (view_off[v + 1] - o != n0) { if (threadIdx.x == 0) flags[2] = 1; return; }
+        for (int i = threadIdx.x; i < n0; i += 128)
+            if (point_id[o + i] != point_id[o0 + i]) flags[2] = 1;
+    }
+}
+
 // Jacobi scales of the shared unknowns, s_j^2 = 1 / (1 + sqrt(d_j))^2 (or 1), from the diagonal the assembly left in E:
 // made on the device so that a solve's set-up uploads nothing
 __global__ void k_shared_scales(const double *__restrict__ dU, double *__restrict__ s2, int n, int jacobi) {
@@ -1061,21 +1089,13 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     if (d->n_points > CVX_MAX_POINTS) return CVX_ERR_UNSUPPORTED;
     const int V = d->n_views, P = d->n_points, C = d->n_cameras;
     if (d->view_off[0] != 0 || d->view_off[V] != d->n_obs) return CVX_ERR_INVALID_ARG;
+    // the views here; the observation lists (point ids in range, no point twice in a view) on the device, below
     int maxn = 0;
-    {
-        std::vector<int> stamp(P, -1);
-        for (int v = 0; v < V; ++v) {
-            if (d->cam_of_view[v] < 0 || d->cam_of_view[v] >= C) return CVX_ERR_INVALID_ARG;
-            const int n = d->view_off[v + 1] - d->view_off[v];
-            if (n < 0) return CVX_ERR_INVALID_ARG;
-            maxn = std::max(maxn, n);
-            for (int o = d->view_off[v]; o < d->view_off[v + 1]; ++o) {
-                const int pid = d->point_id[o];
-                if (pid < 0 || pid >= P) return CVX_ERR_INVALID_ARG;
-                if (stamp[pid] == v) return CVX_ERR_DUPLICATE_MARKER;
-                stamp[pid] = v;
-            }
-        }
+    for (int v = 0; v < V; ++v) {
+        if (d->cam_of_view[v] < 0 || d->cam_of_view[v] >= C) return CVX_ERR_INVALID_ARG;
+        const int n = d->view_off[v + 1] - d->view_off[v];
+        if (n < 0) return CVX_ERR_INVALID_ARG;
+        maxn = std::max(maxn, n);
     }
     if (maxn > CVX_MAX_MARKERS_PER_VIEW) return CVX_ERR_UNSUPPORTED;
     int ndev = 0;
@@ -1136,18 +1156,8 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         }
         grp_v0.push_back(V);
         h->n_groups = (int)grp_cam.size();
-        // aligned groups: thread tid meets the same point in every view of its group
-        h->aligned = true;
-        for (size_t g = 0; g + 1 < grp_v0.size() && h->aligned; ++g) {
-            const int a0 = grp_v0[g], n0 = d->view_off[a0 + 1] - d->view_off[a0];
-            for (int vv = a0 + 1; vv < grp_v0[g + 1] && h->aligned; ++vv) {
-                if (d->view_off[vv + 1] - d->view_off[vv] != n0 ||
-                    std::memcmp(d->point_id + d->view_off[vv], d->point_id + d->view_off[a0], sizeof(int) * n0) != 0)
-                    h->aligned = false;
-            }
-        }
-        h->k2_lds = sizeof(double) * ((h->aligned ? 0 : (size_t)P * PT_ACC) + (size_t)W * 64 * AROW + (size_t)W * 256 + 256);
-        if (h->k2_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
+        // (whether the groups are aligned -- thread tid meets the same point in every view of its group -- is found on
+        // the device, below, and with it the normal-equation kernel's LDS need)
         const int target_chunks = std::max(1, 256 / std::max(1, h->parts));
         const int gpc = std::max(1, (h->n_groups + target_chunks - 1) / target_chunks);
         int g = 0;
@@ -1196,6 +1206,11 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(h->dupload(&h->d_obs_x, d->obs_x, (size_t)h->N, s));
     CVX_TRY(h->dupload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
     CVX_TRY(h->dupload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
+    int *d_flags = nullptr;
+    CVX_TRY(h->dalloc(&d_flags, 4));
+    CVX_HIP(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
+    if (V) hipLaunchKernelGGL(k_check_views, dim3((unsigned)V), dim3(64), 0, s, h->d_view_off, h->d_point_id, P, d_flags);
+    if (h->n_groups) hipLaunchKernelGGL(k_check_aligned, dim3((unsigned)h->n_groups), dim3(128), 0, s, h->d_view_off, h->d_point_id, h->d_grp_v0, d_flags);
     CVX_TRY(h->dupload(&h->d_chk_row0, chk_row0.data(), chk_row0.size(), s));
     if (!k4tasks.empty()) CVX_TRY(h->dupload(&h->d_k4tasks, k4tasks.data(), k4tasks.size(), s));
     {
@@ -1282,6 +1297,16 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     }
     h->ev_made = true;
     pc.mark("allocations 2, events");
+    {
+        int flags[4] = {0, 0, 0, 0};
+        CVX_HIP(hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, s));
+        CVX_HIP(hipStreamSynchronize(s));
+        if (flags[0]) return CVX_ERR_INVALID_ARG;
+        if (flags[1]) return CVX_ERR_DUPLICATE_MARKER;
+        h->aligned = flags[2] == 0;
+        h->k2_lds = sizeof(double) * ((h->aligned ? 0 : (size_t)P * PT_ACC) + (size_t)W * 64 * AROW + (size_t)W * 256 + 256);
+        if (h->k2_lds > 160 * 1024) return CVX_ERR_UNSUPPORTED;
+    }
     if (pc.on) std::fprintf(stderr, "[cvx prof] arena: %.1f of %.1f MB used, %d buffers outside it\n", h->arena_used / 1048576.0, h->arena_cap / 1048576.0, h->arena_fallbacks);
     CVX_HIP(hipStreamSynchronize(s));
     pc.mark("stream synchronize");
