@@ -505,9 +505,10 @@ def main():
         # ---- what one drop-in refine() costs end to end: a handle's whole life around the solve above ----
         end_to_end = None
         if world == 1:
+            oxf, oyf = d["obs_x"].astype(np.float32), d["obs_y"].astype(np.float32)     # cv::Point2f, as the adaptor hands them over
             for _ in range(2):
                 tl = [time.perf_counter()]
-                g2 = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], CAMERAS,
+                g2 = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], oxf, oyf, CAMERAS,
                                    BOARD_W * BOARD_H, device=local_rank, prepare_inner=True)
                 tl.append(time.perf_counter())
                 g2.set_params(intr0, d["poses_init"], pts0)
@@ -519,7 +520,7 @@ def main():
             end_to_end = {"create_ms": 1e3 * (tl[1] - tl[0]), "set_and_solve_ms": 1e3 * (tl[2] - tl[1]),
                           "get_and_destroy_ms": 1e3 * (tl[3] - tl[2]), "total_ms": 1e3 * (tl[3] - tl[0]),
                           "iterations": fs2.iterations, "inner_iteration_steps": fs2.num_inner_iteration_steps,
-                          "note": "cvx_calib_create (26 MB of observations uploaded from pageable memory) -> set_params -> "
+                          "note": "cvx_calib_create (13 MB uploaded from pageable memory: float observations, int point ids) -> set_params -> "
                                   "cvx_calib_solve with the reference's options, first use of the inner iterations included "
                                   "(its host half prepared on a host thread from inside create) -> get_params -> destroy"}
 

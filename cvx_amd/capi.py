@@ -66,7 +66,8 @@ class CalibDesc(C.Structure):
     _fields_ = [("n_cameras", C.c_int), ("n_views", C.c_int), ("n_points", C.c_int), ("n_obs", C.c_int64),
                 ("cam_of_view", ip), ("view_off", ip), ("point_id", ip), ("obs_x", dp), ("obs_y", dp),
                 ("fix_k3", C.c_int), ("fix_intrinsics", C.c_int), ("fix_points", C.c_int),
-                ("device", C.c_int), ("stream", C.c_void_p), ("prepare_inner_iterations", C.c_int)]
+                ("device", C.c_int), ("stream", C.c_void_p), ("obs_xf", fp), ("obs_yf", fp),
+                ("prepare_inner_iterations", C.c_int)]
 
 
 class ToolBADesc(C.Structure):

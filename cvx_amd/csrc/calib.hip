@@ -56,6 +56,11 @@ __global__ void k_fill(double *p, long long n, double v) {
     if (i < n) p[i] = v;
 }
 
+__global__ void k_widen(const float *__restrict__ xy, double *__restrict__ x, double *__restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { x[i] = (double)xy[i]; y[i] = (double)xy[n + i]; }
+}
+
 __global__ void __launch_bounds__(64) k_view_ids(const int *__restrict__ view_off, int *__restrict__ view_id) {
     const int v = blockIdx.x;
     for (int o = view_off[v] + threadIdx.x; o < view_off[v + 1]; o += 64) view_id[o] = v;
@@ -1084,7 +1089,8 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     PhaseClock pc;
     if (d->n_cameras < 1 || d->n_cameras > CVX_MAX_CAMERAS || d->n_views < 0 || d->n_points < 1 || d->n_obs < 0)
         return CVX_ERR_INVALID_ARG;
-    if (!d->cam_of_view || !d->view_off || (d->n_obs > 0 && (!d->point_id || !d->obs_x || !d->obs_y)))
+    const bool obs_f32 = !d->obs_x && !d->obs_y && d->obs_xf && d->obs_yf;
+    if (!d->cam_of_view || !d->view_off || (d->n_obs > 0 && (!d->point_id || (!obs_f32 && (!d->obs_x || !d->obs_y)))))
         return CVX_ERR_INVALID_ARG;
     if (d->n_points > CVX_MAX_POINTS) return CVX_ERR_UNSUPPORTED;
     const int V = d->n_views, P = d->n_points, C = d->n_cameras;
@@ -1203,8 +1209,13 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(h->dupload(&h->d_point_id, d->point_id, (size_t)h->N, s));
     CVX_TRY(h->dalloc(&h->d_view_id, (size_t)h->N));       // every observation's view: made on the device from the offsets
     if (V) hipLaunchKernelGGL(k_view_ids, dim3((unsigned)V), dim3(64), 0, s, h->d_view_off, h->d_view_id);
-    CVX_TRY(h->dupload(&h->d_obs_x, d->obs_x, (size_t)h->N, s));
-    CVX_TRY(h->dupload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
+    if (!obs_f32) {
+        CVX_TRY(h->dupload(&h->d_obs_x, d->obs_x, (size_t)h->N, s));
+        CVX_TRY(h->dupload(&h->d_obs_y, d->obs_y, (size_t)h->N, s));
+    } else {
+        CVX_TRY(h->dalloc(&h->d_obs_x, (size_t)h->N));
+        CVX_TRY(h->dalloc(&h->d_obs_y, (size_t)h->N));
+    }
     CVX_TRY(h->dupload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
     int *d_flags = nullptr;
     CVX_TRY(h->dalloc(&d_flags, 4));
@@ -1244,6 +1255,20 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     }
     const size_t zn = ((size_t)6 * V + 8) * h->ZC;
     CVX_TRY(h->dalloc(&h->d_Z, zn));
+    if (obs_f32 && h->N) {
+        // float observations: staged in memory that is idle until the first linearisation (Z), widened on the device
+        float *stage = reinterpret_cast<float *>(h->d_Z);
+        float *own = nullptr;
+        if (2 * (size_t)h->N * sizeof(float) > zn * sizeof(double)) { CVX_HIP(hipMalloc((void **)&own, 2 * (size_t)h->N * sizeof(float))); stage = own; }
+        hipError_t e = hipMemcpyAsync(stage, d->obs_xf, (size_t)h->N * sizeof(float), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(stage + h->N, d->obs_yf, (size_t)h->N * sizeof(float), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_widen, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, s, stage, h->d_obs_x, h->d_obs_y, (long long)h->N);
+            e = hipGetLastError();
+        }
+        if (own) { (void)hipStreamSynchronize(s); (void)hipFree(own); }
+        CVX_HIP(e);
+    }
     CVX_HIP(hipMemsetAsync(h->d_Z, 0, zn * sizeof(double), s));
     CVX_TRY(h->dalloc(&h->d_Linv, 21 * (size_t)V));
     CVX_TRY(h->dalloc(&h->d_Dv, 6 * (size_t)V));

@@ -15,13 +15,18 @@ class Calib:
     def __init__(self, cam_of_view, view_off, point_id, obs_x, obs_y, n_cameras, n_points,
                  fix_k3=True, fix_intrinsics=False, fix_points=False, device=0, stream=None, prepare_inner=False):
         self.cam_of_view = i32(cam_of_view); self.view_off = i32(view_off); self.point_id = i32(point_id)
-        self.obs_x = f64(obs_x); self.obs_y = f64(obs_y)
+        # float32 observations (cv::Point2f as the reference holds them) go up as they are: half the upload
+        f32 = getattr(obs_x, "dtype", None) == np.float32 and getattr(obs_y, "dtype", None) == np.float32
+        self.obs_x = np.ascontiguousarray(obs_x) if f32 else f64(obs_x)
+        self.obs_y = np.ascontiguousarray(obs_y) if f32 else f64(obs_y)
         self.C, self.P = int(n_cameras), int(n_points)
         self.V, self.N = len(self.cam_of_view), len(self.point_id)
+        as_f = lambda a: a.ctypes.data_as(capi.fp)
         d = capi.CalibDesc(self.C, self.V, self.P, self.N, pi(self.cam_of_view), pi(self.view_off),
-                           pi(self.point_id), pd(self.obs_x), pd(self.obs_y),
+                           pi(self.point_id), None if f32 else pd(self.obs_x), None if f32 else pd(self.obs_y),
                            int(fix_k3), int(fix_intrinsics), int(fix_points), int(device),
-                           C.c_void_p(stream) if stream else None, int(prepare_inner))
+                           C.c_void_p(stream) if stream else None, as_f(self.obs_x) if f32 else None,
+                           as_f(self.obs_y) if f32 else None, int(prepare_inner))
         self.h = C.c_void_p()
         check(lib().cvx_calib_create(C.byref(d), C.byref(self.h)), "cvx_calib_create")
         self.ns = lib().cvx_calib_num_shared(self.h)

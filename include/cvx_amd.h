@@ -125,13 +125,15 @@ typedef struct {
     const int *cam_of_view;   /* [n_views] */
     const int *view_off;      /* [n_views + 1] CSR offsets into the observation arrays */
     const int *point_id;      /* [n_obs]  Marker::id_  (pattern.hpp:23) */
-    const double *obs_x;      /* [n_obs]  Marker::pt_.x promoted to double (calibration.cpp:393) */
+    const double *obs_x;      /* [n_obs]  Marker::pt_.x promoted to double (calibration.cpp:393); or NULL: obs_xf / obs_yf */
     const double *obs_y;
     int fix_k3;               /* 1 in the reference (calibration.cpp:410-415) */
     int fix_intrinsics;       /* refine(..., intrinsics = false), calibration.cpp:407-408 */
     int fix_points;           /* 0 in the reference (board points are free blocks, calibration.cpp:397) */
     int device;               /* HIP device ordinal */
     void *stream;             /* hipStream_t to run on, or NULL: the handle creates its own */
+    const float *obs_xf;      /* [n_obs] Marker::pt_ as the reference holds it (cv::Point2f), read when obs_x is NULL: */
+    const float *obs_yf;      /* half the upload, the promotion to double (calibration.cpp:312-313) made on the device */
     int prepare_inner_iterations; /* 1: the host half of the inner iterations' first use (Ceres' ordering of the blocks
                                * into independent sets, the points' observation lists: ~2 ms at 1 M observations) starts
                                * on a host thread inside cvx_calib_create, beside its uploads -- for callers that go on

@@ -88,12 +88,15 @@ double refine(const Data &data, Camera &cam, std::vector<Mat4> &extrinsics, bool
     const int V = (int)data.markers_.size(), P = (int)data.coords_.size();
     if ((int)extrinsics.size() < V) throw std::runtime_error("refine: fewer extrinsics than views");
     std::vector<int> cam_of_view(V, 0), view_off(V + 1, 0), point_id;
-    std::vector<double> ox, oy;
+    std::vector<float> ox, oy;                  // cv::Point2f as it is: promoted to double (calibration.cpp:393) on the device
+    size_t n_obs = 0;
+    for (int i = 0; i < V; ++i) n_obs += data.markers_[i].size();
+    point_id.reserve(n_obs); ox.reserve(n_obs); oy.reserve(n_obs);
     for (int i = 0; i < V; ++i) {
         for (const auto &m : data.markers_[i]) {
             point_id.push_back(m.id_);
-            ox.push_back((double)m.pt_.x);      // cv::Point2f promoted to double, calibration.cpp:393
-            oy.push_back((double)m.pt_.y);
+            ox.push_back((float)m.pt_.x);
+            oy.push_back((float)m.pt_.y);
         }
         view_off[i + 1] = (int)point_id.size();
     }
@@ -114,7 +117,7 @@ double refine(const Data &data, Camera &cam, std::vector<Mat4> &extrinsics, bool
     cvx_calib_desc d;
     d.n_cameras = 1; d.n_views = V; d.n_points = P; d.n_obs = (int64_t)point_id.size();
     d.cam_of_view = cam_of_view.data(); d.view_off = view_off.data(); d.point_id = point_id.data();
-    d.obs_x = ox.data(); d.obs_y = oy.data();
+    d.obs_x = nullptr; d.obs_y = nullptr; d.obs_xf = ox.data(); d.obs_yf = oy.data();
     d.fix_k3 = 1; d.fix_intrinsics = intrinsics ? 0 : 1; d.fix_points = 0;
     d.device = device; d.stream = stream;
     d.prepare_inner_iterations = 1;                 // the solve below runs with use_inner_iterations (calibration.cpp:424)

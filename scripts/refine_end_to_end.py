@@ -11,10 +11,14 @@ from cvx_amd import capi  # noqa: E402
 
 d = cvx_amd.synth_calib(8, 1250, 12, 9, 20260004)
 x = (d["intr_init"], d["poses_init"], d["points_init"])
+import numpy as np  # noqa: E402
+oxf, oyf = d["obs_x"].astype(np.float32), d["obs_y"].astype(np.float32)     # what the reference holds (cv::Point2f)
+assert np.array_equal(oxf.astype(np.float64), d["obs_x"])
 for rep in range(6):
     ahead = rep >= 3        # the adaptor's way: the inner iterations' host preparation starts inside create
     t0 = time.perf_counter()
-    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 8, 108, prepare_inner=ahead)
+    ox, oy = (oxf, oyf) if ahead else (d["obs_x"], d["obs_y"])
+    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], ox, oy, 8, 108, prepare_inner=ahead)
     t1 = time.perf_counter()
     g.set_params(*x)
     t2 = time.perf_counter()

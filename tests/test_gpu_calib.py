@@ -366,3 +366,20 @@ def test_speculated_steps_stop_at_the_iteration_limit_and_at_tolerances(orc, mon
         assert out[0][4] == out[1][4] and abs(out[0][4] - out[0][2]) <= 1e-12 * out[0][2]
     monkeypatch.delenv("CVX_CALIB_SPECULATE")
     g.close()
+
+
+def test_float_observations_give_the_same_handle(orc):
+    """cvx_calib_desc.obs_xf / obs_yf: cv::Point2f observations uploaded as floats and widened on the device are the
+    doubles the host promotion gives -- cost, residuals and a solve bit for bit"""
+    d = cvx_amd.synth_calib(2, 40, 12, 9, 99, ragged=4)
+    xf, yf = d["obs_x"].astype(np.float32), d["obs_y"].astype(np.float32)
+    assert np.array_equal(xf.astype(np.float64), d["obs_x"])               # the generator rounds to float32 (SURVEY 8d)
+    out = []
+    for ox, oy in ((d["obs_x"], d["obs_y"]), (xf, yf)):
+        g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], ox, oy, 2, 108)
+        g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+        c0 = g.cost()
+        s = g.solve(capi.options("refine"))
+        out.append((c0, s.iterations, s.final_cost, [a.tolist() for a in g.get_params()]))
+        g.close()
+    assert out[0] == out[1]
