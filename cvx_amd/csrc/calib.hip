@@ -527,15 +527,25 @@ void inner_point_lists(const cvx_calib *h, std::vector<int> &pt_off, std::vector
 // cvx_calib_create -- so it can run on a host thread while the caller goes on (start_inner_ahead).
 cvx_calib::InnerHostPrep inner_host_prep(const cvx_calib *h) {
     cvx_calib::InnerHostPrep r;
+    PhaseClock pc;
     const int C = h->C, P = h->P, V = h->V, NB = C + P + V;
     r.group.resize(NB);
+    // the two halves are independent (1.1 and 0.7 ms at config 4): the lists on a thread of their own.  The ordering
+    // checks the tables; the lists index by point id, so they wait for nothing but are only used if it passed.
+    std::future<void> lists;
+    bool ids_ok = true;
+    for (int64_t o = 0; o < h->N && ids_ok; ++o) ids_ok = h->h_point_id[o] >= 0 && h->h_point_id[o] < P;
+    if (ids_ok) lists = std::async(std::launch::async, [h, &r] { inner_point_lists(h, r.pt_off, r.pt_obs); });
     r.status = cvx_calib_inner_ordering(C, V, P, h->h_cam_of_view.data(), h->h_view_off.data(), h->h_point_id.data(), h->fix_intr,
                                         h->fix_pts, r.group.data(), &r.sets);
-    if (r.status) return r;
-    r.types.assign(r.sets, 0);
-    for (int i = 0; i < NB; ++i)
-        if (r.group[i] >= 0) r.types[r.group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
-    inner_point_lists(h, r.pt_off, r.pt_obs);
+    pc.mark("inner host: ordering");
+    if (!r.status) {
+        r.types.assign(r.sets, 0);
+        for (int i = 0; i < NB; ++i)
+            if (r.group[i] >= 0) r.types[r.group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
+    }
+    if (lists.valid()) lists.get();
+    pc.mark("inner host: point lists (wait)");
     return r;
 }
 
@@ -546,6 +556,7 @@ void start_inner_ahead(cvx_calib *h) {
 
 int ensure_inner(cvx_calib *h) {
     if (h->inner_ready) return CVX_OK;
+    PhaseClock pc;
     free_inner(h);
     const int C = h->C, P = h->P, V = h->V, NB = C + P + V;
     const std::vector<int> &point_id = h->h_point_id;
@@ -591,6 +602,7 @@ int ensure_inner(cvx_calib *h) {
         h->inner_sets = r.sets;
         h->inner_types.swap(r.types); group.swap(r.group); pt_off.swap(r.pt_off); pt_obs.swap(r.pt_obs);
     }
+    pc.mark("inner: host half (or its wait)");
     hipStream_t s = h->stream;
     // a point's list is cut so that a workgroup of 256 lanes sees about two observations per lane
     h->pt_slices = (int)std::min<int64_t>(64, std::max<int64_t>(1, h->N / P / 512));
@@ -616,6 +628,7 @@ int ensure_inner(cvx_calib *h) {
         for (int k = 0; k < 10; ++k) { *dv[k] = dp; dp += up(std::max<size_t>(d_sizes[k], 1), 32); }
         h->d_ib_out = h->d_ib_active + 4;       // the first eight doubles: running count | pad | four of the pass's own
     }
+    pc.mark("inner: allocations");
     CVX_HIP(hipMemcpyAsync(h->d_pt_off, pt_off.data(), pt_off.size() * sizeof(int), hipMemcpyHostToDevice, s));
     if (N) CVX_HIP(hipMemcpyAsync(h->d_pt_obs, pt_obs.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
     CVX_HIP(hipMemcpyAsync(h->d_blk_group, group.data(), group.size() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -627,7 +640,9 @@ int ensure_inner(cvx_calib *h) {
     CVX_HIP(hipMemsetAsync(h->d_ib_flag, 0, 4 * (size_t)NB * sizeof(int), s));
     CVX_HIP(hipMemsetAsync(h->d_ib_st, 0, (size_t)NB * cvxi::IB_STATE * sizeof(double), s));
     if (!h->h_ib_active) CVX_HIP(hipHostMalloc((void **)&h->h_ib_active, 4 * sizeof(double), hipHostMallocDefault));
+    pc.mark("inner: uploads, gather enqueued");
     CVX_HIP(hipStreamSynchronize(s));       // the uploads read host vectors that end here
+    pc.mark("inner: synchronize");
     h->inner_ready = true;
     return CVX_OK;
 }
