@@ -535,7 +535,11 @@ cvx_calib::InnerHostPrep inner_host_prep(const cvx_calib *h) {
     std::future<void> lists;
     bool ids_ok = true;
     for (int64_t o = 0; o < h->N && ids_ok; ++o) ids_ok = h->h_point_id[o] >= 0 && h->h_point_id[o] < P;
-    if (ids_ok) lists = std::async(std::launch::async, [h, &r] { inner_point_lists(h, r.pt_off, r.pt_obs); });
+    bool lists_inline = false;
+    if (ids_ok) {
+        try { lists = std::async(std::launch::async, [h, &r] { inner_point_lists(h, r.pt_off, r.pt_obs); }); }
+        catch (...) { lists_inline = true; }        // no thread to be had: one after the other
+    }
     r.status = cvx_calib_inner_ordering(C, V, P, h->h_cam_of_view.data(), h->h_view_off.data(), h->h_point_id.data(), h->fix_intr,
                                         h->fix_pts, r.group.data(), &r.sets);
     pc.mark("inner host: ordering");
@@ -545,13 +549,15 @@ cvx_calib::InnerHostPrep inner_host_prep(const cvx_calib *h) {
             if (r.group[i] >= 0) r.types[r.group[i]] |= 1 << (i < C ? cvxi::IB_CAM : i < C + P ? cvxi::IB_POINT : cvxi::IB_POSE);
     }
     if (lists.valid()) lists.get();
+    else if (lists_inline && !r.status) inner_point_lists(h, r.pt_off, r.pt_obs);
     pc.mark("inner host: point lists (wait)");
     return r;
 }
 
 void start_inner_ahead(cvx_calib *h) {
     if (h->inner_ready || h->inner_ahead.valid() || h->nranks > 1) return;
-    h->inner_ahead = std::async(std::launch::async, inner_host_prep, (const cvx_calib *)h);
+    try { h->inner_ahead = std::async(std::launch::async, inner_host_prep, (const cvx_calib *)h); }
+    catch (...) {}      // no thread to be had: the first use makes it itself
 }
 
 int ensure_inner(cvx_calib *h) {
