@@ -235,11 +235,7 @@ cvx_calib::~cvx_calib() {
     if (arena) (void)hipFree(arena);
     pc.mark("  device frees");
     if (h_E) (void)hipHostFree(h_E);
-    if (h_params) (void)hipHostFree(h_params);
-    if (h_ds_emb) (void)hipHostFree(h_ds_emb);
-    if (h_E2) (void)hipHostFree(h_E2);
-    if (h_lm) (void)hipHostFree(h_lm);
-    if (h_ib_active) (void)hipHostFree(h_ib_active);
+    if (h_E2) (void)hipHostFree(h_E2);          // heads the handle's one pinned block: h_lm, h_ib_active, h_ds_emb, h_params behind it
     pc.mark("  pinned frees");
     if (ev_made)
         for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
@@ -645,7 +641,6 @@ int ensure_inner(cvx_calib *h) {
     }
     CVX_HIP(hipMemsetAsync(h->d_ib_flag, 0, 4 * (size_t)NB * sizeof(int), s));
     CVX_HIP(hipMemsetAsync(h->d_ib_st, 0, (size_t)NB * cvxi::IB_STATE * sizeof(double), s));
-    if (!h->h_ib_active) CVX_HIP(hipHostMalloc((void **)&h->h_ib_active, 4 * sizeof(double), hipHostMallocDefault));
     pc.mark("inner: uploads, gather enqueued");
     CVX_HIP(hipStreamSynchronize(s));       // the uploads read host vectors that end here
     pc.mark("inner: synchronize");
@@ -1272,7 +1267,6 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         CVX_HIP(hipMemsetAsync(h->d_poses[0], 0, 2 * (size_t)h->poses_step * sizeof(double), s));
         CVX_TRY(h->dalloc(&h->d_lm, 1));
         CVX_HIP(hipMemsetAsync(h->d_lm, 0, sizeof(LmDev), s));
-        CVX_HIP(hipHostMalloc((void **)&h->h_lm, sizeof(LmDev), hipHostMallocDefault));
     }
     const size_t zn = ((size_t)6 * V + 8) * h->ZC;
     CVX_TRY(h->dalloc(&h->d_Z, zn));
@@ -1309,7 +1303,6 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(alloc_exchange(h));
     pc.mark("alloc_exchange");
     CVX_TRY(h->dalloc(&h->d_ds_emb, (size_t)C * h->ZC));
-    CVX_HIP(hipHostMalloc((void **)&h->h_ds_emb, sizeof(double) * (size_t)C * h->ZC, hipHostMallocDefault));
     CVX_TRY(h->dalloc(&h->d_dposes, 6 * (size_t)V));
     CVX_TRY(h->dalloc(&h->d_out_view, 3 * (size_t)V));
     h->n_cost_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (h->N + 255) / 256));
@@ -1319,7 +1312,19 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(h->dalloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
     // two records of 32 doubles (a speculated step may publish while the host still reads the one before)
-    CVX_HIP(hipHostMalloc((void **)&h->h_E2, 64 * sizeof(double), hipHostMallocMapped));
+    {
+        // one pinned, host-mapped block: the step's two records (polled) | the speculated steps' staging record | the
+        // inner iterations' counters | the embedded step | the parameter staging of set_params / get_params
+        const size_t n_lm = (sizeof(LmDev) + 7) / 8, n_emb = (size_t)C * h->ZC, n_par = 9 * (size_t)C + 3 * (size_t)P + 6 * (size_t)V;
+        auto up8 = [](size_t n) { return (n + 7) / 8 * 8; };
+        const size_t total = 64 + up8(n_lm) + 8 + up8(n_emb) + up8(std::max<size_t>(n_par, 1));
+        CVX_HIP(hipHostMalloc((void **)&h->h_E2, total * sizeof(double), hipHostMallocMapped));
+        double *q = h->h_E2 + 64;
+        h->h_lm = reinterpret_cast<LmDev *>(q); q += up8(n_lm);
+        h->h_ib_active = q; q += 8;
+        h->h_ds_emb = q; q += up8(n_emb);
+        h->h_params = q;
+    }
     std::memset(h->h_E2, 0, 64 * sizeof(double));
     if (hipHostGetDevicePointer((void **)&h->d_E2_map, h->h_E2, 0) != hipSuccess) h->d_E2_map = nullptr;
     // damped reduced solve: (ns + 1) rows (the right-hand side rides as row ns), padded to 32-tiles
@@ -1335,8 +1340,6 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     h->fin_lds = sizeof(double) * cvxs::finish_lds_doubles(h->ns);
 #undef CVX_TRY
     hipLaunchKernelGGL(k_fill, dim3((std::max(1, h->ns) + 255) / 256), dim3(256), 0, s, h->d_s2sh, (long long)std::max(1, h->ns), 1.0);
-    CVX_HIP(hipHostMalloc((void **)&h->h_params, sizeof(double) * std::max<size_t>(1, 9 * (size_t)h->C + 3 * (size_t)h->P + 6 * (size_t)h->V),
-                          hipHostMallocDefault));
     for (int i = 0; i < PH_COUNT; ++i) {
         CVX_HIP(hipEventCreate(&h->ev[i][0]));
         CVX_HIP(hipEventCreate(&h->ev[i][1]));
