@@ -23,7 +23,8 @@ struct cvx_homography {
     size_t lds_bytes = 0;
     ~cvx_homography() {
         (void)hipSetDevice(device);
-        for (void *p : {(void *)d_off, (void *)d_ret, (void *)d_pts, (void *)d_H, (void *)d_info, (void *)d_W, (void *)d_res})
+        // d_pts heads the handle's one device block (offsets, estimates, info, return values behind it)
+        for (void *p : {(void *)d_pts, (void *)d_W, (void *)d_res})
             if (p) (void)hipFree(p);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -56,11 +57,19 @@ extern "C" int cvx_homography_create(int n_problems, const int *off, const float
     else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     h->lds_bytes = hom_lds_doubles(max_points < 4 ? 4 : max_points) * sizeof(double);
     const size_t tp = (size_t)(total > 0 ? total : 1);
-    CVX_HIP(hipMalloc(&h->d_off, sizeof(int) * (n_problems + 1)));
-    CVX_HIP(hipMalloc(&h->d_ret, sizeof(int) * n_problems));
-    CVX_HIP(hipMalloc(&h->d_pts, sizeof(float) * 4 * tp));
-    CVX_HIP(hipMalloc(&h->d_H, sizeof(double) * 9 * n_problems));
-    CVX_HIP(hipMalloc(&h->d_info, sizeof(double) * 10 * n_problems));
+    {
+        // one device block, carved on 256-byte boundaries: points | H | info | offsets | return values
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t b_pts = up(sizeof(float) * 4 * tp), b_H = up(sizeof(double) * 9 * n_problems), b_info = up(sizeof(double) * 10 * n_problems),
+                     b_off = up(sizeof(int) * ((size_t)n_problems + 1)), b_ret = up(sizeof(int) * (size_t)n_problems);
+        char *base = nullptr;
+        CVX_HIP(hipMalloc((void **)&base, b_pts + b_H + b_info + b_off + b_ret));
+        h->d_pts = reinterpret_cast<float *>(base); base += b_pts;
+        h->d_H = reinterpret_cast<double *>(base); base += b_H;
+        h->d_info = reinterpret_cast<double *>(base); base += b_info;
+        h->d_off = reinterpret_cast<int *>(base); base += b_off;
+        h->d_ret = reinterpret_cast<int *>(base);
+    }
     CVX_HIP(hipMemsetAsync(h->d_H, 0, sizeof(double) * 9 * n_problems, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_off, off, sizeof(int) * (n_problems + 1), hipMemcpyHostToDevice, h->stream));
     if (total > 0) {

@@ -31,11 +31,9 @@ struct cvx_toolba {
     int rank = 0, nranks = 1, xdev = 0;
     ~cvx_toolba() {
         (void)hipSetDevice(device);
-        for (void *p : {(void *)d_obs, (void *)d_view, (void *)d_jobs, (void *)d_job_first, (void *)d_trans,
-                        (void *)d_params, (void *)d_intr, (void *)d_partial, (void *)d_cpartial, (void *)d_out})
-            if (p) (void)hipFree(p);
+        // d_obs heads the handle's one device block, h_out its one pinned block
+        if (d_obs) (void)hipFree(d_obs);
         if (h_out) (void)hipHostFree(h_out);
-        if (h_params) (void)hipHostFree(h_params);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -534,18 +532,24 @@ extern "C" int cvx_toolba_create(const cvx_toolba_desc *d, cvx_toolba **out) {
     std::vector<int> jobs(3 * (size_t)std::max(n_jobs, 1), 0);
     for (int j = 0; j < n_jobs; ++j) { jobs[j] = jp[j]; jobs[n_jobs + j] = js[j]; jobs[2 * (size_t)n_jobs + j] = jc[j]; }
     const size_t nv = (size_t)std::max(V, 1);
-    CVX_HIP(hipMalloc((void **)&h->d_obs, 2 * n * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_view, n * sizeof(int)));
-    CVX_HIP(hipMalloc((void **)&h->d_jobs, jobs.size() * sizeof(int)));
-    CVX_HIP(hipMalloc((void **)&h->d_job_first, ((size_t)P + 1) * sizeof(int)));
-    CVX_HIP(hipMalloc((void **)&h->d_trans, nv * 12 * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_params, (7 + 3 * (size_t)P) * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_intr, 9 * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_partial, (size_t)std::max(n_jobs, 1) * TBA_ACC * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_cpartial, (size_t)std::max(n_jobs, 1) * sizeof(double)));
-    CVX_HIP(hipMalloc((void **)&h->d_out, ((size_t)P * TBA_ACC + 8) * sizeof(double)));
-    CVX_HIP(hipHostMalloc((void **)&h->h_out, ((size_t)P * TBA_ACC + 8) * sizeof(double), hipHostMallocDefault));
-    CVX_HIP(hipHostMalloc((void **)&h->h_params, (7 + 3 * (size_t)P) * sizeof(double), hipHostMallocDefault));
+    {
+        // one device block and one pinned block per handle, carved on 256-byte boundaries (ten hipMalloc / hipFree pairs
+        // cost more than the tool's whole solve at its usual sizes)
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t nj = (size_t)std::max(n_jobs, 1), n_out = (size_t)P * TBA_ACC + 8, n_par = 7 + 3 * (size_t)P;
+        const size_t sizes[10] = {2 * n * sizeof(double), n * sizeof(int), jobs.size() * sizeof(int), ((size_t)P + 1) * sizeof(int),
+                                  nv * 12 * sizeof(double), n_par * sizeof(double), 9 * sizeof(double), nj * TBA_ACC * sizeof(double),
+                                  nj * sizeof(double), n_out * sizeof(double)};
+        size_t total = 0;
+        for (size_t b : sizes) total += up(b);
+        char *base = nullptr;
+        CVX_HIP(hipMalloc((void **)&base, total));
+        void **slots[10] = {(void **)&h->d_obs, (void **)&h->d_view, (void **)&h->d_jobs, (void **)&h->d_job_first, (void **)&h->d_trans,
+                            (void **)&h->d_params, (void **)&h->d_intr, (void **)&h->d_partial, (void **)&h->d_cpartial, (void **)&h->d_out};
+        for (int k = 0; k < 10; ++k) { *slots[k] = base; base += up(sizes[k]); }
+        CVX_HIP(hipHostMalloc((void **)&h->h_out, (n_out + n_par) * sizeof(double), hipHostMallocDefault));
+        h->h_params = h->h_out + n_out;
+    }
     CVX_HIP(hipMemcpyAsync(h->d_obs, obs.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_view, view.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
