@@ -353,6 +353,7 @@ int launch_schur(cvx_calib *h) {
 // spec: a speculated step (calib_kernels.h, LmDev) -- the current point's tables are there by construction (the step
 // before made its candidate's), K2 and the assembly read the record
 int linearize(cvx_calib *h, const cvx_damping &d, bool init_mode, bool write_scale, bool spec = false) {
+    if (h->V == 0) { cvx::set_last_error("the handle holds no views: nothing to linearise"); return CVX_ERR_INVALID_ARG; }
     int st = spec ? CVX_OK : launch_pose_prepare(h, h->cur);
     if (st) return st;
     K2Args a = make_k2(h, d, spec);
@@ -1547,6 +1548,14 @@ extern "C" int cvx_calib_set_exchange(cvx_calib *h, cvx_allreduce_fn fn, void *c
 extern "C" int cvx_calib_solve(cvx_calib *h, const cvx_lm_options *opt, cvx_lm_summary *summary) {
     if (!h || !opt || !summary) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
+    if (h->V == 0) {
+        // no residual block at all: the solve of an empty problem, as for views without markers (on a sharded handle
+        // this rank could not take part in the exchanges: refused)
+        if (h->nranks > 1) { cvx::set_last_error("a rank of a sharded solve holds no views"); return CVX_ERR_INVALID_ARG; }
+        std::memset(summary, 0, sizeof *summary);
+        summary->termination = 1;
+        return CVX_OK;
+    }
     // the host half of the inner iterations' first use runs beside the initial linearisation and the first step
     if (opt->inner_iterations && opt->strategy == 0) start_inner_ahead(h);
     CalibEvaluator ev(h);

@@ -383,3 +383,25 @@ def test_float_observations_give_the_same_handle(orc):
         out.append((c0, s.iterations, s.final_cost, [a.tolist() for a in g.get_params()]))
         g.close()
     assert out[0] == out[1]
+
+
+def test_problems_without_residuals():
+    """no views at all, or only views without markers: create works, the cost is 0, the solve returns at once with the
+    parameters untouched (the reference would hand Ceres a problem without residual blocks)"""
+    i32 = lambda a: np.array(a, dtype=np.int32)
+    intr = np.array([[1000.0, 1000, 640, 480, 0, 0, 0, 0, 0]])
+    pts = np.array([[0.0, 0, 0], [25, 0, 0], [0, 25, 0], [25, 25, 0]])
+    for cam, off in ((i32([]), i32([0])), (i32([0, 0]), i32([0, 0, 0]))):
+        V = len(cam)
+        for ahead in (False, True):
+            g = cvx_amd.Calib(cam, off, i32([]), np.zeros(0), np.zeros(0), 1, 4, prepare_inner=ahead)
+            poses = np.tile(np.array([0.01, 0.02, 0.03, 0.0, 0.0, 500.0]), (V, 1)).reshape(V, 6)
+            g.set_params(intr, poses, pts)
+            assert g.cost() == 0.0
+            s = g.solve(capi.options("refine"))
+            assert s.iterations == 0 and s.termination == 1 and s.final_cost == 0.0
+            io, po, xo = g.get_params()
+            assert np.array_equal(io, intr) and np.array_equal(po, poses) and np.array_equal(xo, pts)
+            assert g.inner_pass() == 0.0 and g.cost() == 0.0       # a pass over blocks without residuals moves nothing
+            assert all(np.array_equal(a, b) for a, b in zip(g.get_params(), (intr, poses, pts)))
+            g.close()
