@@ -30,3 +30,22 @@ for name, cam, off, pid, ox, P in (
             print("%-26s ahead=%d cost %.4g | %s" % (name, ahead, c, res))
         except capi.CvxError as e:
             print("%-26s ahead=%d create refused: %s" % (name, ahead, e))
+
+# ---- the other handles ----
+from cvx_amd.problem import HomographyBatch
+for n in (0, 1, 2):
+    try:
+        q = (np.tile([1.0, 0, 0, 0], (n, 1)), np.zeros((n, 3)), np.tile([1.0, 0, 0, 0], (n, 1)), np.zeros((n, 3)))
+        he = cvx_amd.HandEye(*q)
+        p, s = he.solve(np.array([1.0, 0, 0, 0, 0, 0, 0]), capi.options("handeye"))
+        print("hand-eye, %d pairs: %d iterations, termination %d, cost %.3g" % (n, s.iterations, s.termination, s.final_cost))
+        he.close()
+    except capi.CvxError as e:
+        print("hand-eye, %d pairs: refused: %s" % (n, e))
+try:
+    b = HomographyBatch(i32([0, 0, 0]), np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32))
+    H = b.dlt(); b.run(); Hr, info, ret = b.get(); r = b.residuals()
+    print("homography, two empty problems: dlt", H.tolist(), "ret", ret.tolist(), "residuals", r.shape)
+    b.close()
+except capi.CvxError as e:
+    print("homography, empty problems: refused: %s" % e)
