@@ -158,6 +158,7 @@ struct cvx_calib {
     int npad = 32, nT = 1;
     double *d_A = nullptr, *d_s2sh = nullptr, *d_Ds = nullptr, *d_delta_s = nullptr;
     int *d_fail = nullptr;
+    int *d_flags = nullptr;          // cvx_calib_create's device-side checks: id out of range | point twice in a view | groups not aligned
     size_t fin_lds = 0;
     std::vector<double> h_A;
     // inner iterations (inner_kernels.h), made on first use
@@ -229,7 +230,7 @@ cvx_calib::~cvx_calib() {
     void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_points[0], d_poses[0], d_rt[0], d_lm, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
-                    d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
+                    d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_flags, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
     for (void *p : ptrs)
         if (p && !in_arena(p)) (void)hipFree(p);
     if (arena) (void)hipFree(arena);
@@ -1234,7 +1235,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         CVX_TRY(h->dalloc(&h->d_obs_y, (size_t)h->N));
     }
     CVX_TRY(h->dupload(&h->d_grp_v0, grp_v0.data(), grp_v0.size(), s));
-    int *d_flags = nullptr;
+    int *&d_flags = h->d_flags;
     CVX_TRY(h->dalloc(&d_flags, 4));
     CVX_HIP(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), s));
     if (V) hipLaunchKernelGGL(k_check_views, dim3((unsigned)V), dim3(64), 0, s, h->d_view_off, h->d_point_id, P, d_flags);
