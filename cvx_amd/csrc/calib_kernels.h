@@ -21,6 +21,15 @@ namespace cvxk {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// 16-byte accesses with the non-temporal hint, for buffers that are written once and read once (or read for the last
+// time): they pass the L2 and the memory-side cache by instead of pushing out what the next kernels come back for
+typedef double cvx_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store2(double *p, double a, double b) { __builtin_nontemporal_store(cvx_d2v{a, b}, (cvx_d2v *)p); }
+__device__ __forceinline__ double2 nt_load2(const double *p) {
+    const cvx_d2v v = __builtin_nontemporal_load((const cvx_d2v *)p);
+    return double2{v.x, v.y};
+}
+
 constexpr int RT_STRIDE = 40;    // per view: R[9] | dR/dw_j [3][9] | t[3] | pad
 constexpr int PT_ACC = 36;       // per point accumulators: Ucx[9][3] | Uxx[6] | gx[3]
 constexpr int AROW = 17;         // LDS stride (doubles) of one staged Jacobian row: odd, so that the 64 lanes' row writes spread over all banks
@@ -655,6 +664,7 @@ __global__ void __launch_bounds__(T, K2_MIN_WAVES) k_normal_eq(K2Args a) {
             // points the group never sees keep the zeros the slab was created with
             if (v0 < v1 && tid < a.view_off[v0 + 1] - a.view_off[v0]) {
 #pragma unroll
+                // (plain stores: as non-temporal 8-byte pieces 288 bytes apart they made the kernel 20 us slower)
                 for (int i = 0; i < PT_ACC; ++i) sp[pid * PT_ACC + i] = pacc[i];
             }
         } else {
@@ -1095,8 +1105,11 @@ __device__ __forceinline__ void k4_body(const K4Args &a, const K4Task t, int chu
     auto put = [&](int gA, int gB, const double (&v)[4]) {
         const int q = gA * nb - gA * (gA - 1) / 2 + (gB - gA);
         double *out = a.slab + ((size_t)chunk * a.nblk + q) * 256 + 2 * lane;      // k4_slot order
-        *(double2 *)(out) = double2{v[0], v[1]};
-        *(double2 *)(out + 128) = double2{v[2], v[3]};
+        // non-temporal: the slab (60 MB at config 4) is written once and read once by the sums; kept out of the caches it
+        // leaves Z there for the back substitution and the observations for the next linearisation (measured in
+        // bench.py: K3 -2 us, K2 -4 us, back substitution -2 us against plain stores)
+        nt_store2(out, v[0], v[1]);
+        nt_store2(out + 128, v[2], v[3]);
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1215,6 +1228,10 @@ struct ReduceArgs {
     int *fail;      // factorisation flag of the reduced solve, cleared here for this linear step
 };
 
+// the slabs are read exactly once: non-temporal loads (with the slab's non-temporal stores and the back substitution's
+// non-temporal reads of Z: 0.400 -> 0.388 ms per LM iteration at config 4)
+__device__ __forceinline__ double2 sum_load2(const double *p) { return nt_load2(p); }
+
 __device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, double (*part)[128]) {
     if (j.wide) {
         // short lists (the Schur tiles: one entry per chunk of the camera): 2 KB coalesced rows, no LDS, sixteen
@@ -1228,14 +1245,14 @@ __device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, 
         for (; q + 16 <= q1; q += 16) {
             double2 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = *(const double2 *)(j.src + (size_t)j.list[q + u] * j.stride + e);
+            for (int u = 0; u < 16; ++u) v[u] = sum_load2(j.src + (size_t)j.list[q + u] * j.stride + e);
             s.x += (((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x))) +
                    (((v[8].x + v[9].x) + (v[10].x + v[11].x)) + ((v[12].x + v[13].x) + (v[14].x + v[15].x)));
             s.y += (((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y))) +
                    (((v[8].y + v[9].y) + (v[10].y + v[11].y)) + ((v[12].y + v[13].y) + (v[14].y + v[15].y)));
         }
         for (; q < q1; ++q) {
-            const double2 v = *(const double2 *)(j.src + (size_t)j.list[q] * j.stride + e);
+            const double2 v = sum_load2(j.src + (size_t)j.list[q] * j.stride + e);
             s.x += v.x; s.y += v.y;
         }
         *(double2 *)(j.dst + (size_t)c * j.n_out + e) = s;
@@ -1253,12 +1270,12 @@ __device__ __forceinline__ void group_sum_block(const SumJob &j, int bx, int c, 
         for (; q + 8 <= a1; q += 8) {       // eight independent loads in flight
             double2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const double2 *)(j.src + (size_t)j.list[q + u] * j.stride + e);
+            for (int u = 0; u < 8; ++u) v[u] = sum_load2(j.src + (size_t)j.list[q + u] * j.stride + e);
             s.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
             s.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
         }
         for (; q < a1; ++q) {
-            const double2 v = *(const double2 *)(j.src + (size_t)j.list[q] * j.stride + e);
+            const double2 v = sum_load2(j.src + (size_t)j.list[q] * j.stride + e);
             s.x += v.x; s.y += v.y;
         }
     }

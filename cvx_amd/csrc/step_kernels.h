@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(BSC_THREADS, 5) k_backsubst_cost_step(const do
         const double dx = step_emb(f, x, cam, c), dy = step_emb(f, x, cam, c + 1);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const double2 z = *(const double2 *)(Zv + (size_t)i * ZC + c);
+            const double2 z = nt_load2(Zv + (size_t)i * ZC + c);      // Z's last reader: non-temporal (40.3 -> 36.9 us)
             t[i] += z.x * dx + z.y * dy;
         }
     }
