@@ -1,6 +1,8 @@
-// Does a kernel's plain WRITE of a buffer leave it in the 256 MiB Infinity Cache for the next kernel's read?  Times a
-// streaming read of B bytes after (a) a plain-store write of the buffer, (b) a non-temporal-store write, (c) a read of
-// it, (d) nothing recent (a 512 MB sweep in between).  Reads: 16 B per lane, every byte summed (no elision).
+// Does a kernel's WRITE of a buffer leave it in the 256 MiB Infinity Cache for the next kernel's read?  A streaming read
+// cannot tell (HBM and the cache both feed it at ~6 TB/s); a latency-bound one can: one wave per CU, every lane one
+// dependent 16-byte load after the other over its own slice (hit 227 ns, HBM miss ~3x that: MI355X_MICROARCH.md).
+// The buffer is made by stores of a given cache policy (plain | nt | sc1 | sc0 sc1), or by a plain read (the control:
+// known to leave it resident), behind a 512 MB sweep that empties the cache.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/mall_probe.hip -o scripts/micro/mall_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -8,17 +10,32 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 typedef double d2v __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(256) k_write(double *p, size_t n2, int nt) {
+template <int POLICY>
+__global__ void __launch_bounds__(256) k_write(double *p, size_t n2) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
         const d2v v = {(double)i, 1.0};
-        if (nt) __builtin_nontemporal_store(v, (d2v *)p + i); else ((d2v *)p)[i] = v;
+        d2v *q = (d2v *)p + i;
+        if (POLICY == 0) *q = v;
+        else if (POLICY == 1) __builtin_nontemporal_store(v, q);
+        else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");
     }
 }
-__global__ void __launch_bounds__(256) k_read(const double *p, size_t n2, double *sink, int nt) {
+__global__ void __launch_bounds__(256) k_stream(const double *p, size_t n2, double *sink) {
     double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
-        const d2v v = nt ? __builtin_nontemporal_load((const d2v *)p + i) : ((const d2v *)p)[i];
-        s += v.x + v.y;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) { const d2v v = ((const d2v *)p)[i]; s += v.x + v.y; }
+    if (s == 1.2345) sink[0] = s;
+}
+// latency-bound: 256 workgroups of one wave; a lane walks `steps` lines of its slice, each address depending on the
+// value before (the data is (double)index, so the dependency is real but the walk is a plain stride)
+__global__ void __launch_bounds__(64) k_chase(const double *p, size_t n2, int steps, double *sink) {
+    const size_t lanes = (size_t)gridDim.x * 64, me = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t i = me * 8 % n2;          // 128-byte lines: 8 x 16 B
+    double s = 0.0;
+    for (int k = 0; k < steps; ++k) {
+        const d2v v = ((const d2v *)p)[i];
+        s += v.y;
+        i = ((size_t)v.x + lanes * 8) % n2;       // v.x == i: next line of this lane, lanes * 128 bytes further on
     }
     if (s == 1.2345) sink[0] = s;
 }
@@ -29,19 +46,22 @@ int main(int argc, char **argv) {
     double *buf, *other, *sink;
     CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&other, big)); CK(hipMalloc(&sink, 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto timed_read = [&](int nt) { float ms = 0; hipEventRecord(e0, 0); hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, 0, buf, n2, sink, nt);
-                                    hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); return ms; };
-    auto sweep = [&]() { hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, 0, other, big / 16, sink, 0); };
-    hipLaunchKernelGGL(k_write, dim3(2048), dim3(256), 0, 0, other, big / 16, 0);
+    const int steps = (int)(n2 / 8 / (256 * 64));          // every line of the buffer once
+    auto chase = [&]() { float ms = 0; (void)hipEventRecord(e0, 0); hipLaunchKernelGGL(k_chase, dim3(256), dim3(64), 0, 0, buf, n2, steps, sink);
+                         (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); return 1e6 * ms / steps; };
+    auto sweep = [&]() { hipLaunchKernelGGL(k_stream, dim3(2048), dim3(256), 0, 0, other, big / 16, sink); };
+    hipLaunchKernelGGL(k_write<0>, dim3(2048), dim3(256), 0, 0, other, big / 16);
+    hipLaunchKernelGGL(k_write<0>, dim3(2048), dim3(256), 0, 0, buf, n2);
     for (int rep = 0; rep < 3; ++rep) {
-        sweep(); hipLaunchKernelGGL(k_write, dim3(2048), dim3(256), 0, 0, buf, n2, 0); const float a = timed_read(0);
-        sweep(); hipLaunchKernelGGL(k_write, dim3(2048), dim3(256), 0, 0, buf, n2, 1); const float b = timed_read(0);
-        sweep(); hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, 0, buf, n2, sink, 0); const float c = timed_read(0);
-        sweep(); const float d = timed_read(0);
-        sweep(); hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, 0, buf, n2, sink, 1); const float e = timed_read(0);
+        sweep(); const float cold = chase();
+        sweep(); hipLaunchKernelGGL(k_stream, dim3(2048), dim3(256), 0, 0, buf, n2, sink); const float rd = chase();
+        sweep(); hipLaunchKernelGGL(k_write<0>, dim3(2048), dim3(256), 0, 0, buf, n2); const float w0 = chase();
+        sweep(); hipLaunchKernelGGL(k_write<1>, dim3(2048), dim3(256), 0, 0, buf, n2); const float w1 = chase();
+        sweep(); hipLaunchKernelGGL(k_write<2>, dim3(2048), dim3(256), 0, 0, buf, n2); const float w2 = chase();
+        sweep(); hipLaunchKernelGGL(k_write<3>, dim3(2048), dim3(256), 0, 0, buf, n2); const float w3 = chase();
         CK(hipDeviceSynchronize());
-        printf("%zu MB read: after plain write %.1f us (%.2f TB/s) | after nt write %.1f us | after a read %.1f us (%.2f TB/s) | cold %.1f us (%.2f TB/s) | after an nt read %.1f us\n",
-               mb, 1e3 * a, bytes / (a * 1e9), 1e3 * b, 1e3 * c, bytes / (c * 1e9), 1e3 * d, bytes / (d * 1e9), 1e3 * e);
+        printf("%zu MB, ns per dependent load: cold %.0f | after a streaming read %.0f | after a write: plain %.0f, nt %.0f, sc1 %.0f, sc0 sc1 %.0f\n",
+               mb, cold, rd, w0, w1, w2, w3);
     }
     return 0;
 }
