@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(T, K2_MIN_WAVES) k_normal_eq(K2Args a) {
 #ifdef K2_WALL
     w_pro = wall_clock64();
 #endif
+    int rt_touch = 0;
     for (int v = v0; v < v1; ++v) {
 #ifdef K2_PROF
         tp = clock64();
@@ -498,6 +499,13 @@ __global__ void __launch_bounds__(T, K2_MIN_WAVES) k_normal_eq(K2Args a) {
         const int base = as_uniform(a.view_off)[v];
         const int n = as_uniform(a.view_off)[v + 1] - base;
         const uniform_f64 rt = as_uniform(a.rt + (size_t)v * RT_STRIDE);
+        {
+            // the NEXT view's table touched now (one scalar load per 64-byte line of its 320 bytes), so that its loads
+            // hit the scalar cache a view later: the functor needs the table at once, and the table was written by
+            // another kernel, i.e. comes from the Infinity Cache or further (K2 88.7 -> 86.9 us in bench.py)
+            const uniform_i32 nx = (uniform_i32)(a.rt + (size_t)(v + 1 < v1 ? v + 1 : v) * RT_STRIDE);
+            rt_touch ^= nx[0] ^ nx[16] ^ nx[32] ^ nx[48] ^ nx[64] ^ nx[79];
+        }
         const bool active = tid < n;
         double r[2] = {0.0, 0.0}, Jp[12], Jc[18], Jx[6];
         if (active) {
@@ -653,6 +661,7 @@ __global__ void __launch_bounds__(T, K2_MIN_WAVES) k_normal_eq(K2Args a) {
 #ifdef K2_WALL
     w_loop = wall_clock64();
 #endif
+    asm volatile("" :: "s"(rt_touch));      // (keeps the touching loads alive)
     // ---- flush the group's accumulators ----
     double *sp = a.slab_pt + (size_t)g * a.P * PT_ACC;
 #ifdef K2_NO_PACC
