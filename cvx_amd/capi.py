@@ -102,6 +102,7 @@ SIGNATURES = {
     "cvx_partition_views": (C.c_int, [C.c_int, ip, C.c_int, ip]),
     "cvx_calib_create": (C.c_int, [C.POINTER(CalibDesc), C.POINTER(C.c_void_p)]),
     "cvx_calib_prepare_inner_iterations": (C.c_int, [C.c_void_p]),
+    "cvx_release_cached_memory": (C.c_int, []),
     "cvx_calib_destroy": (None, [C.c_void_p]),
     "cvx_calib_set_params": (C.c_int, [C.c_void_p, dp, dp, dp]),
     "cvx_calib_get_params": (C.c_int, [C.c_void_p, dp, dp, dp]),

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <future>
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +35,41 @@ struct PhaseClock {
         t = n;
     }
 };
+
+// One freed arena per device is kept for the next cvx_calib_create (a drop-in refine() is create -> solve -> destroy, and
+// freeing / mapping a few hundred MB costs 0.3-0.4 ms of a 6.5 ms call): at most ARENA_KEEP_MAX bytes, handed back to the
+// runtime by cvx_release_cached_memory() or when a larger block takes its place; CVX_ARENA_CACHE=0 switches it off.
+// Nothing relies on what a block holds (tests run with the arena poisoned, CVX_POISON_ARENA=1).  The caller has
+// synchronised the stream of the handle that gives a block back, so no kernel still uses it.
+constexpr size_t ARENA_KEEP_MAX = (size_t)1 << 30;
+struct ArenaCache {
+    std::mutex mu;
+    char *p[16] = {};
+    size_t cap[16] = {};
+} g_arena_cache;
+bool arena_cache_on() {
+    static const bool on = [] { const char *e = std::getenv("CVX_ARENA_CACHE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// a kept block of at least `need` bytes (and not more than twice that: a small problem does not sit on a large block)
+char *arena_take(int dev, size_t need, size_t *cap) {
+    if (!arena_cache_on() || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_arena_cache.mu);
+    if (!g_arena_cache.p[dev] || g_arena_cache.cap[dev] < need || g_arena_cache.cap[dev] > 2 * need + ((size_t)8 << 20)) return nullptr;
+    char *p = g_arena_cache.p[dev];
+    *cap = g_arena_cache.cap[dev];
+    g_arena_cache.p[dev] = nullptr; g_arena_cache.cap[dev] = 0;
+    return p;
+}
+// the device of `dev` is current
+void arena_give(int dev, char *p, size_t cap) {
+    if (!p) return;
+    if (arena_cache_on() && dev >= 0 && dev < 16 && cap <= ARENA_KEEP_MAX) {
+        std::lock_guard<std::mutex> lock(g_arena_cache.mu);
+        if (g_arena_cache.cap[dev] < cap) { std::swap(p, g_arena_cache.p[dev]); std::swap(cap, g_arena_cache.cap[dev]); }
+    }
+    if (p) (void)hipFree(p);
+}
 
 template <class Tp>
 int dev_alloc(Tp **p, size_t n) {
@@ -233,7 +269,7 @@ cvx_calib::~cvx_calib() {
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_flags, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
     for (void *p : ptrs)
         if (p && !in_arena(p)) (void)hipFree(p);
-    if (arena) (void)hipFree(arena);
+    arena_give(device, arena, arena_cap);
     pc.mark("  device frees");
     if (h_E) (void)hipHostFree(h_E);
     if (h_E2) (void)hipHostFree(h_E2);          // heads the handle's one pinned block: h_lm, h_ib_active, h_ds_emb, h_params behind it
@@ -1217,10 +1253,16 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
                                Q * h->nblk * 256 + (size_t)C * P * PT_ACC + (size_t)C * h->nblk * 256 + (size_t)C * 256 +
                                (size_t)C * h->ZC + 2048 + 16 + 2 * npad_ * npad_ + 3 * (size_t)std::max(1, h->ns);
         h->arena_cap = ints * sizeof(int) + doubles * sizeof(double) + k4tasks.size() * sizeof(K4Task) + sizeof(LmDev) + 64 * 256 + 65536;
-        if (hipMalloc((void **)&h->arena, h->arena_cap) != hipSuccess) {     // no arena: every buffer on its own
+        size_t kept = 0;
+        h->arena = arena_take(h->device, h->arena_cap, &kept);
+        if (h->arena) h->arena_cap = kept;
+        else if (hipMalloc((void **)&h->arena, h->arena_cap) != hipSuccess) {     // no arena: every buffer on its own
             (void)hipGetLastError();
             h->arena = nullptr; h->arena_cap = 0;
         }
+        // CVX_POISON_ARENA=1 (development): every byte 0xFF -- NaN for doubles, -1 for integers -- so that a buffer read
+        // before it is written shows in the tests instead of passing on memory that happens to come back zeroed
+        if (h->arena && std::getenv("CVX_POISON_ARENA")) CVX_HIP(hipMemsetAsync(h->arena, 0xFF, h->arena_cap, s));
     }
     CVX_TRY(h->dupload(&h->d_view_off, d->view_off, (size_t)V + 1, s));
     CVX_TRY(h->dupload(&h->d_cam_of_view, d->cam_of_view, (size_t)V, s));
@@ -1362,6 +1404,22 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_HIP(hipStreamSynchronize(s));
     pc.mark("stream synchronize");
     *out = guard.release();
+    return CVX_OK;
+}
+
+extern "C" int cvx_release_cached_memory(void) {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (int dev = 0; dev < 16; ++dev) {
+        char *p = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_arena_cache.mu);
+            std::swap(p, g_arena_cache.p[dev]);
+            g_arena_cache.cap[dev] = 0;
+        }
+        if (p) { (void)hipSetDevice(dev); (void)hipFree(p); }
+    }
+    if (have) (void)hipSetDevice(cur);
     return CVX_OK;
 }
 

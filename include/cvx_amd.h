@@ -152,6 +152,11 @@ int cvx_calib_create(const cvx_calib_desc *desc, cvx_calib **out);
  * it is under way or done, and on view-sharded handles, whose first use is a collective).  cvx_calib_solve starts it
  * itself when its options ask for inner iterations, beside the initial linearisation. */
 int cvx_calib_prepare_inner_iterations(cvx_calib *h);
+/* cvx_calib_destroy keeps the handle's device memory (one block per device, at most 1 GiB) for the next
+ * cvx_calib_create of a similar size instead of freeing it: the reference's refine() is one call, i.e. create -> solve ->
+ * destroy here, and un-mapping / mapping a few hundred MB is 0.4 ms of it.  This hands the kept blocks back to the
+ * runtime; CVX_ARENA_CACHE=0 in the environment switches the keeping off. */
+int cvx_release_cached_memory(void);
 void cvx_calib_destroy(cvx_calib *h);
 
 /* parameter blocks in the reference's layouts: intrinsics[n_cameras][9] in the order

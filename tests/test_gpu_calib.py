@@ -405,3 +405,36 @@ def test_problems_without_residuals():
             assert g.inner_pass() == 0.0 and g.cost() == 0.0       # a pass over blocks without residuals moves nothing
             assert all(np.array_equal(a, b) for a, b in zip(g.get_params(), (intr, poses, pts)))
             g.close()
+
+
+def test_kept_device_block_and_poisoned_arena():
+    """cvx_calib_destroy keeps its device block for the next create (cvx_release_cached_memory hands it back), and no
+    kernel reads a buffer before it is written: a solve on a fresh block, on a kept one (stale data of a different
+    problem) and on one filled with 0xFF bytes (CVX_POISON_ARENA: NaN doubles, -1 integers) are the same bit for bit"""
+    import os
+    L = capi.lib()
+    d = cvx_amd.synth_calib(2, 30, 12, 9, 123, ragged=3)
+    other = cvx_amd.synth_calib(3, 25, 12, 9, 124)
+    args = (d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 2, 108)
+    runs = []
+    try:
+        for mode in ("fresh", "kept", "poisoned"):
+            if mode == "fresh":
+                assert L.cvx_release_cached_memory() == 0
+            if mode == "kept":          # a slightly larger problem leaves its block behind
+                g = cvx_amd.Calib(other["cam_of_view"], other["view_off"], other["point_id"], other["obs_x"], other["obs_y"], 3, 108)
+                g.set_params(other["intr_init"], other["poses_init"], other["points_init"])
+                g.solve(capi.options("refine"))
+                g.close()
+            if mode == "poisoned":
+                os.environ["CVX_POISON_ARENA"] = "1"
+            g = cvx_amd.Calib(*args)
+            g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+            s = g.solve(capi.options("refine"))
+            runs.append((s.iterations, s.termination, s.num_inner_iteration_steps, s.final_cost, s.trace()["cost"].tolist(),
+                         [a.tolist() for a in g.get_params()]))
+            g.close()
+    finally:
+        os.environ.pop("CVX_POISON_ARENA", None)
+    assert runs[0][0] > 3 and runs[1] == runs[0] and runs[2] == runs[0]
+    assert L.cvx_release_cached_memory() == 0 and L.cvx_release_cached_memory() == 0      # idempotent
