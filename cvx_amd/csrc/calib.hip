@@ -47,10 +47,7 @@ struct ArenaCache {
     char *p[16] = {};
     size_t cap[16] = {};
 } g_arena_cache;
-bool arena_cache_on() {
-    static const bool on = [] { const char *e = std::getenv("CVX_ARENA_CACHE"); return !(e && e[0] == '0'); }();
-    return on;
-}
+bool arena_cache_on() { return cvx::handle_cache_on(); }
 // a kept block of at least `need` bytes (and not more than twice that: a small problem does not sit on a large block)
 char *arena_take(int dev, size_t need, size_t *cap) {
     if (!arena_cache_on() || dev < 0 || dev >= 16) return nullptr;
@@ -179,6 +176,8 @@ struct cvx_calib {
     double *d_slab_pt = nullptr, *d_slab_cam = nullptr, *d_grp_scal = nullptr, *d_slab_tile = nullptr;
     double *d_Tpt = nullptr, *d_Tt = nullptr, *d_Gcam = nullptr;
     double *d_E = nullptr, *h_E = nullptr;
+    double *d_E_res = nullptr, *h_E_res = nullptr;   // E's places in the arena / the pinned block, good for up to E_res_count doubles
+    size_t E_res_count = 0;
     double *h_params = nullptr;      // pinned: 9 C + 3 P + 6 V doubles, set_params / get_params stage through it
     double *d_X = nullptr;           // ranks > 1: the exchanged buffer (packed lower triangle of S + the tail of E); h_E stages it
     size_t X_count = 0, X_tail = 0;
@@ -263,7 +262,11 @@ cvx_calib::~cvx_calib() {
     if (inner_ahead.valid()) inner_ahead.wait();     // the thread reads this handle's host tables
     (void)hipSetDevice(device);
     PhaseClock pc;
-    void *ptrs[] = {d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
+    // nothing of this handle in flight when its block and its stream go to the next one (a failed create may leave work)
+    bool idle = true;
+    if (stream && hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); idle = false; }
+    if (d_E == d_E_res) d_E_res = nullptr;       // (one buffer, listed once below)
+    void *ptrs[] = {d_E_res, d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_points[0], d_poses[0], d_rt[0], d_lm, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
                     d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_flags, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
@@ -271,13 +274,16 @@ cvx_calib::~cvx_calib() {
         if (p && !in_arena(p)) (void)hipFree(p);
     arena_give(device, arena, arena_cap);
     pc.mark("  device frees");
-    if (h_E) (void)hipHostFree(h_E);
+    if (h_E && h_E != h_E_res) (void)hipHostFree(h_E);
     if (h_E2) (void)hipHostFree(h_E2);          // heads the handle's one pinned block: h_lm, h_ib_active, h_ds_emb, h_params behind it
     pc.mark("  pinned frees");
     if (ev_made)
         for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
     if (ev_step) (void)hipEventDestroy(ev_step);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (own_stream && stream) {
+        if (idle) cvx::stream_give(device, stream);
+        else (void)hipStreamDestroy(stream);
+    }
     pc.mark("  events, stream");
 }
 
@@ -523,8 +529,8 @@ int exchange_sum_host(cvx_calib *h, std::vector<double> &v) {
 }
 
 void free_inner(cvx_calib *h) {
-    if (h->d_ib_iblock) (void)hipFree(h->d_ib_iblock);
-    if (h->d_ib_dblock) (void)hipFree(h->d_ib_dblock);
+    if (h->d_ib_iblock && !h->in_arena(h->d_ib_iblock)) (void)hipFree(h->d_ib_iblock);
+    if (h->d_ib_dblock && !h->in_arena(h->d_ib_dblock)) (void)hipFree(h->d_ib_dblock);
     h->d_ib_iblock = nullptr; h->d_ib_dblock = nullptr;
     h->d_pt_off = h->d_pt_obs = h->d_blk_group = h->d_ib_flag = h->d_pt_view = h->d_pt_cam = nullptr;
     h->d_ib_active = h->d_ib_H = h->d_ib_st = h->d_ib_xc = h->d_ib_cc = h->d_ib_slab = h->d_ib_out = h->d_ib_ptslab = h->d_ib_X = nullptr;
@@ -656,8 +662,9 @@ int ensure_inner(cvx_calib *h) {
     size_t i_tot = 0, d_tot = 0;
     for (size_t n : i_sizes) i_tot += up(std::max<size_t>(n, 1), 64);
     for (size_t n : d_sizes) d_tot += up(std::max<size_t>(n, 1), 32);
-    st = dev_alloc(&h->d_ib_iblock, i_tot); if (st) return st;
-    st = dev_alloc(&h->d_ib_dblock, d_tot); if (st) return st;
+    // from the arena when cvx_calib_create left room for them (desc.prepare_inner_iterations), else allocations of their own
+    st = h->dalloc(&h->d_ib_iblock, i_tot); if (st) return st;
+    st = h->dalloc(&h->d_ib_dblock, d_tot); if (st) return st;
     {
         int *ip = h->d_ib_iblock;
         int **iv[] = {&h->d_pt_off, &h->d_pt_obs, &h->d_pt_view, &h->d_pt_cam, &h->d_blk_group, &h->d_ib_flag};
@@ -1113,14 +1120,20 @@ private:
 
 
 int alloc_exchange(cvx_calib *h) {
-    if (h->d_E) { (void)hipFree(h->d_E); h->d_E = nullptr; }
-    if (h->h_E) { (void)hipHostFree(h->h_E); h->h_E = nullptr; }
+    int st = CVX_OK;
+    if (h->d_E && h->d_E != h->d_E_res) (void)hipFree(h->d_E);
+    if (h->h_E && h->h_E != h->h_E_res) (void)hipHostFree(h->h_E);
+    h->d_E = nullptr; h->h_E = nullptr;
     h->E_scal = (size_t)h->ns * h->ns + 3 * (size_t)h->ns;
     h->E_count = h->E_scal + 2 + 2 * (size_t)h->nranks;
-    int st = dev_alloc(&h->d_E, h->E_count);
-    if (st) return st;
+    if (h->d_E_res && h->h_E_res && h->E_count <= h->E_res_count) {
+        h->d_E = h->d_E_res; h->h_E = h->h_E_res;       // (the usual case: no allocation)
+    } else {
+        st = dev_alloc(&h->d_E, h->E_count);
+        if (st) return st;
+        CVX_HIP(hipHostMalloc((void **)&h->h_E, h->E_count * sizeof(double), hipHostMallocDefault));
+    }
     CVX_HIP(hipMemsetAsync(h->d_E, 0, h->E_count * sizeof(double), h->stream));
-    CVX_HIP(hipHostMalloc((void **)&h->h_E, h->E_count * sizeof(double), hipHostMallocDefault));
     if (h->d_X) { (void)hipFree(h->d_X); h->d_X = nullptr; }
     h->X_tail = (size_t)h->ns * (h->ns + 1) / 2;
     h->X_count = h->X_tail + (h->E_count - (size_t)h->ns * h->ns);
@@ -1173,7 +1186,12 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     h->fix_k3 = d->fix_k3 ? 1 : 0; h->fix_intr = d->fix_intrinsics ? 1 : 0; h->fix_pts = d->fix_points ? 1 : 0;
     h->device = d->device;
     if (d->stream) h->stream = (hipStream_t)d->stream;
-    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    else {
+        h->own_stream = true;
+        const int sst = cvx::own_stream_begin(d->device, &h->stream);
+        if (sst) return sst;
+    }
+    pc.mark("  stream");
     h->cam_free = h->fix_intr ? 0 : 1;
     h->pts_free = h->fix_pts ? 0 : 1;
     h->ncf = h->fix_intr ? 0 : (h->fix_k3 ? 8 : 9);
@@ -1200,7 +1218,9 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     h->h_cam_of_view.assign(d->cam_of_view, d->cam_of_view + V);
     h->h_view_off.assign(d->view_off, d->view_off + V + 1);
     if (d->n_obs) h->h_point_id.assign(d->point_id, d->point_id + d->n_obs);
+    pc.mark("  host copies of the lists");
     if (d->prepare_inner_iterations) start_inner_ahead(h);      // beside the rest of this function
+    pc.mark("  inner preparation started");
 
     // groups (K2 workgroups) and chunks (K3 row ranges): contiguous views of one camera
     std::vector<int> grp_v0, grp_cam, chk_row0, chk_cam;
@@ -1251,8 +1271,16 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         const size_t doubles = 2 * Nn + 2 * (up32(9 * (size_t)C) + up32(3 * (size_t)P) + up32(6 * Vn) + up32(Vn * RT_STRIDE)) +
                                (6 * Vn + 8) * h->ZC + (21 + 6 * 3 + 6 + 3 + 1) * Vn + G * P * PT_ACC + G * 256 + G * 4 +
                                Q * h->nblk * 256 + (size_t)C * P * PT_ACC + (size_t)C * h->nblk * 256 + (size_t)C * 256 +
-                               (size_t)C * h->ZC + 2048 + 16 + 2 * npad_ * npad_ + 3 * (size_t)std::max(1, h->ns);
+                               (size_t)C * h->ZC + 2048 + 16 + 2 * npad_ * npad_ + 3 * (size_t)std::max(1, h->ns) +
+                               ((size_t)h->ns * h->ns + 3 * (size_t)h->ns + 2 + 2 * 64);
         h->arena_cap = ints * sizeof(int) + doubles * sizeof(double) + k4tasks.size() * sizeof(K4Task) + sizeof(LmDev) + 64 * 256 + 65536;
+        if (d->prepare_inner_iterations) {
+            // room for the inner iterations' two blocks (ensure_inner: point-major copies of the observations, block state)
+            const size_t NB = (size_t)C + P + Vn, slices = (size_t)std::min<int64_t>(64, std::max<int64_t>(1, h->N / P / 512));
+            h->arena_cap += sizeof(int) * (((size_t)P + 1) + 3 * Nn + 5 * NB + 6 * 64) +
+                            sizeof(double) * (8 + NB * (cvxi::IB_STRIDE + cvxi::IB_STATE + 10) + (G + 1 + C + P) * cvxi::IB_STRIDE +
+                                              (size_t)P * slices * cvxi::PT_SLOT + 2 * Nn + 10 * 32) + 2 * 256;
+        }
         size_t kept = 0;
         h->arena = arena_take(h->device, h->arena_cap, &kept);
         if (h->arena) h->arena_cap = kept;
@@ -1264,6 +1292,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         // before it is written shows in the tests instead of passing on memory that happens to come back zeroed
         if (h->arena && std::getenv("CVX_POISON_ARENA")) CVX_HIP(hipMemsetAsync(h->arena, 0xFF, h->arena_cap, s));
     }
+    pc.mark("  arena");
     CVX_TRY(h->dupload(&h->d_view_off, d->view_off, (size_t)V + 1, s));
     CVX_TRY(h->dupload(&h->d_cam_of_view, d->cam_of_view, (size_t)V, s));
     CVX_TRY(h->dupload(&h->d_point_id, d->point_id, (size_t)h->N, s));
@@ -1328,6 +1357,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         if (own) { (void)hipStreamSynchronize(s); (void)hipFree(own); }
         CVX_HIP(e);
     }
+    pc.mark("  parameters, Z, float observations");
     CVX_HIP(hipMemsetAsync(h->d_Z, 0, zn * sizeof(double), s));
     CVX_TRY(h->dalloc(&h->d_Linv, 21 * (size_t)V));
     CVX_TRY(h->dalloc(&h->d_Dv, 6 * (size_t)V));
@@ -1344,6 +1374,24 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(h->dalloc(&h->d_Tt, (size_t)C * h->nblk * 256));
     CVX_TRY(h->dalloc(&h->d_Gcam, (size_t)C * 256));
     pc.mark("allocations 1");
+    {
+        // one pinned, host-mapped block: the step's two records (polled) | the speculated steps' staging record | the
+        // inner iterations' counters | the embedded step | the parameter staging of set_params / get_params | E's staging
+        // copy (its size depends on the number of ranks: room for 64, beyond that alloc_exchange makes its own)
+        const size_t n_lm = (sizeof(LmDev) + 7) / 8, n_emb = (size_t)C * h->ZC, n_par = 9 * (size_t)C + 3 * (size_t)P + 6 * (size_t)V;
+        auto up8 = [](size_t n) { return (n + 7) / 8 * 8; };
+        h->E_res_count = (size_t)h->ns * h->ns + 3 * (size_t)h->ns + 2 + 2 * 64;
+        const size_t total = 64 + up8(n_lm) + 8 + up8(n_emb) + up8(std::max<size_t>(n_par, 1)) + up8(h->E_res_count);
+        CVX_HIP(hipHostMalloc((void **)&h->h_E2, total * sizeof(double), hipHostMallocMapped));
+        double *q = h->h_E2 + 64;
+        h->h_lm = reinterpret_cast<LmDev *>(q); q += up8(n_lm);
+        h->h_ib_active = q; q += 8;
+        h->h_ds_emb = q; q += up8(n_emb);
+        h->h_params = q; q += up8(std::max<size_t>(n_par, 1));
+        h->h_E_res = q;
+        CVX_TRY(h->dalloc(&h->d_E_res, h->E_res_count));
+    }
+    pc.mark("  pinned block");
     CVX_TRY(alloc_exchange(h));
     pc.mark("alloc_exchange");
     CVX_TRY(h->dalloc(&h->d_ds_emb, (size_t)C * h->ZC));
@@ -1356,19 +1404,6 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     CVX_TRY(h->dalloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
     // two records of 32 doubles (a speculated step may publish while the host still reads the one before)
-    {
-        // one pinned, host-mapped block: the step's two records (polled) | the speculated steps' staging record | the
-        // inner iterations' counters | the embedded step | the parameter staging of set_params / get_params
-        const size_t n_lm = (sizeof(LmDev) + 7) / 8, n_emb = (size_t)C * h->ZC, n_par = 9 * (size_t)C + 3 * (size_t)P + 6 * (size_t)V;
-        auto up8 = [](size_t n) { return (n + 7) / 8 * 8; };
-        const size_t total = 64 + up8(n_lm) + 8 + up8(n_emb) + up8(std::max<size_t>(n_par, 1));
-        CVX_HIP(hipHostMalloc((void **)&h->h_E2, total * sizeof(double), hipHostMallocMapped));
-        double *q = h->h_E2 + 64;
-        h->h_lm = reinterpret_cast<LmDev *>(q); q += up8(n_lm);
-        h->h_ib_active = q; q += 8;
-        h->h_ds_emb = q; q += up8(n_emb);
-        h->h_params = q;
-    }
     std::memset(h->h_E2, 0, 64 * sizeof(double));
     if (hipHostGetDevicePointer((void **)&h->d_E2_map, h->h_E2, 0) != hipSuccess) h->d_E2_map = nullptr;
     // damped reduced solve: (ns + 1) rows (the right-hand side rides as row ns), padded to 32-tiles
@@ -1419,6 +1454,7 @@ extern "C" int cvx_release_cached_memory(void) {
         }
         if (p) { (void)hipSetDevice(dev); (void)hipFree(p); }
     }
+    cvx::stream_cache_release();
     if (have) (void)hipSetDevice(cur);
     return CVX_OK;
 }

@@ -40,7 +40,7 @@ struct cvx_handeye {
         for (void *p : {(void *)d_pairs, (void *)d_eval})
             if (p) (void)hipFree(p);
         if (h_out) (void)hipHostFree(h_out);
-        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        if (own_stream) cvx::own_stream_end(device, stream);
     }
 };
 
@@ -297,7 +297,7 @@ extern "C" int cvx_handeye_create(int n_pairs, const double *qa, const double *t
     std::unique_ptr<cvx_handeye> guard(h);
     h->n = n_pairs; h->device = device;
     if (stream) h->stream = (hipStream_t)stream;
-    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    else { h->own_stream = true; const int sst = cvx::own_stream_begin(h->device, &h->stream); if (sst) return sst; }
     h->n_blocks = (int)std::min<long long>(1024, std::max<long long>(1, (h->n + 255) / 256));
     const size_t n = (size_t)n_pairs;
     std::vector<double> planes(14 * std::max<size_t>(n, 1));

@@ -26,7 +26,7 @@ struct cvx_homography {
         // d_pts heads the handle's one device block (offsets, estimates, info, return values behind it)
         for (void *p : {(void *)d_pts, (void *)d_W, (void *)d_res})
             if (p) (void)hipFree(p);
-        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        if (own_stream) cvx::own_stream_end(device, stream);
     }
 };
 
@@ -54,7 +54,7 @@ extern "C" int cvx_homography_create(int n_problems, const int *off, const float
     std::unique_ptr<cvx_homography> h(new cvx_homography);
     h->n = n_problems; h->device = device; h->max_points = max_points; h->total = total;
     if (stream) h->stream = (hipStream_t)stream;
-    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    else { h->own_stream = true; const int sst = cvx::own_stream_begin(h->device, &h->stream); if (sst) return sst; }
     h->lds_bytes = hom_lds_doubles(max_points < 4 ? 4 : max_points) * sizeof(double);
     const size_t tp = (size_t)(total > 0 ? total : 1);
     {

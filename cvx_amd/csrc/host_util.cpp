@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <random>
 #include <set>
 #include <string>
@@ -16,6 +18,42 @@ namespace cvx {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &s) { g_last_error = s; }
+
+bool handle_cache_on() {
+    static const bool on = [] { const char *e = std::getenv("CVX_ARENA_CACHE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+namespace {
+struct StreamCache {
+    std::mutex mu;
+    hipStream_t s[16] = {};
+} g_streams;
+}  // namespace
+hipStream_t stream_take(int dev) {
+    if (!handle_cache_on() || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_streams.mu);
+    hipStream_t s = g_streams.s[dev];
+    g_streams.s[dev] = nullptr;
+    return s;
+}
+void stream_give(int dev, hipStream_t s) {
+    if (!s) return;
+    if (handle_cache_on() && dev >= 0 && dev < 16) {
+        std::lock_guard<std::mutex> lock(g_streams.mu);
+        if (!g_streams.s[dev]) { g_streams.s[dev] = s; return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+void stream_cache_release() {
+    for (int dev = 0; dev < 16; ++dev) {
+        hipStream_t s = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_streams.mu);
+            std::swap(s, g_streams.s[dev]);
+        }
+        if (s) { (void)hipSetDevice(dev); (void)hipStreamDestroy(s); }
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // SPD solve.  Left-looking blocked Cholesky on the lower triangle (row-major): every entry

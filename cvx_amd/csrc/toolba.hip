@@ -34,7 +34,7 @@ struct cvx_toolba {
         // d_obs heads the handle's one device block, h_out its one pinned block
         if (d_obs) (void)hipFree(d_obs);
         if (h_out) (void)hipHostFree(h_out);
-        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        if (own_stream) cvx::own_stream_end(device, stream);
     }
 };
 
@@ -528,7 +528,7 @@ extern "C" int cvx_toolba_create(const cvx_toolba_desc *d, cvx_toolba **out) {
     std::unique_ptr<cvx_toolba> h(new cvx_toolba);
     h->V = V; h->P = P; h->N = N; h->device = d->device; h->n_jobs = n_jobs; h->huber = d->huber;
     if (d->stream) h->stream = (hipStream_t)d->stream;
-    else { CVX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    else { h->own_stream = true; const int sst = cvx::own_stream_begin(h->device, &h->stream); if (sst) return sst; }
     std::vector<int> jobs(3 * (size_t)std::max(n_jobs, 1), 0);
     for (int j = 0; j < n_jobs; ++j) { jobs[j] = jp[j]; jobs[n_jobs + j] = js[j]; jobs[2 * (size_t)n_jobs + j] = jc[j]; }
     const size_t nv = (size_t)std::max(V, 1);

@@ -438,3 +438,32 @@ def test_kept_device_block_and_poisoned_arena():
         os.environ.pop("CVX_POISON_ARENA", None)
     assert runs[0][0] > 3 and runs[1] == runs[0] and runs[2] == runs[0]
     assert L.cvx_release_cached_memory() == 0 and L.cvx_release_cached_memory() == 0      # idempotent
+
+
+def test_kept_stream_goes_to_one_handle_at_a_time():
+    """a handle that ends leaves its stream for the next one on the device (common.h stream_take / stream_give): two
+    handles alive together -- the first on the kept stream, the second on a new one -- solve as a lone handle does, and
+    ending both (one stream kept, one destroyed) leaves a library that still creates and solves"""
+    L = capi.lib()
+    d = cvx_amd.synth_calib(2, 12, 9, 6, 321)
+    args = (d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], 2, 54)
+
+    def run(g):
+        g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+        s = g.solve(capi.options("refine"))
+        return s.iterations, s.final_cost, [a.tolist() for a in g.get_params()]
+
+    assert L.cvx_release_cached_memory() == 0
+    g = cvx_amd.Calib(*args)
+    lone = run(g)
+    g.close()                                   # its stream and its block are kept
+    a, b = cvx_amd.Calib(*args), cvx_amd.Calib(*args)
+    ra, rb = run(a), run(b)
+    assert run(a) == ra                         # and again, interleaved with the other handle's work
+    a.close(); b.close()
+    assert ra == lone and rb == lone
+    g = cvx_amd.Calib(*args)
+    assert run(g) == lone
+    g.close()
+    assert L.cvx_release_cached_memory() == 0
+
