@@ -154,8 +154,10 @@ int cvx_calib_create(const cvx_calib_desc *desc, cvx_calib **out);
 int cvx_calib_prepare_inner_iterations(cvx_calib *h);
 /* cvx_calib_destroy keeps the handle's device memory (one block per device, at most 1 GiB) for the next
  * cvx_calib_create of a similar size instead of freeing it: the reference's refine() is one call, i.e. create -> solve ->
- * destroy here, and un-mapping / mapping a few hundred MB is 0.4 ms of it.  This hands the kept blocks back to the
- * runtime; CVX_ARENA_CACHE=0 in the environment switches the keeping off. */
+ * destroy here, and un-mapping / mapping a few hundred MB is 0.4 ms of it.  A handle of any kind that made its own stream
+ * (desc.stream NULL) likewise leaves it, idle, for the next handle on the device (one per device): creating a stream and
+ * the first copies on it cost 0.1-5 ms.  This hands the kept blocks and streams back to the runtime; CVX_ARENA_CACHE=0
+ * in the environment switches the keeping off. */
 int cvx_release_cached_memory(void);
 void cvx_calib_destroy(cvx_calib *h);
 

@@ -467,3 +467,37 @@ def test_kept_stream_goes_to_one_handle_at_a_time():
     g.close()
     assert L.cvx_release_cached_memory() == 0
 
+
+def test_handles_made_and_ended_on_two_host_threads():
+    """the kept block and the kept stream are process-wide (a mutex each); two host threads that create, solve and destroy
+    handles side by side -- each of them sometimes taking what the other just left -- get what one thread gets"""
+    import threading
+    d = cvx_amd.synth_calib(2, 12, 9, 6, 322)
+    oxf, oyf = d["obs_x"].astype(np.float32), d["obs_y"].astype(np.float32)
+
+    def once(prepare):
+        g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], oxf, oyf, 2, 54, prepare_inner=prepare)
+        g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+        s = g.solve(capi.options("refine"))
+        out = (s.iterations, s.final_cost, [a.tolist() for a in g.get_params()])
+        g.close()
+        return out
+
+    lone = once(False)
+    results, errors = [[], []], []
+
+    def worker(k):
+        try:
+            for i in range(6):
+                results[k].append(once((i + k) % 2 == 0))
+        except Exception as e:          # noqa: BLE001 -- reported below, in the test's thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    assert all(r == lone for rs in results for r in rs) and len(results[0]) == len(results[1]) == 6
+
