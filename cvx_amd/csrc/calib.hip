@@ -183,7 +183,7 @@ struct cvx_calib {
     size_t X_count = 0, X_tail = 0;
     size_t E_count = 0, E_scal = 0;
     double *d_ds_emb = nullptr, *h_ds_emb = nullptr, *d_dposes = nullptr, *d_out_view = nullptr;
-    double *d_cost_partial = nullptr, *d_cost_view = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
+    double *d_cost_partial = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
     hipEvent_t ev_step = nullptr;
     double *d_E2_map = nullptr;      // device view of h_E2 (host-mapped, fine-grained)
     long long step_seq = 0;
@@ -268,7 +268,7 @@ cvx_calib::~cvx_calib() {
     if (d_E == d_E_res) d_E_res = nullptr;       // (one buffer, listed once below)
     void *ptrs[] = {d_E_res, d_view_off, d_cam_of_view, d_point_id, d_view_id, d_grp_v0, d_chk_row0, d_clist, d_clist_off, d_glist,
                     d_glist_off, d_obs_x, d_obs_y, d_intr[0], d_points[0], d_poses[0], d_rt[0], d_lm, d_Z, d_Linv, d_Dv, d_gv, d_s2pose, d_slab_pt, d_slab_cam, d_grp_scal,
-                    d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial, d_cost_view,
+                    d_slab_tile, d_Tpt, d_Tt, d_Gcam, d_E, d_ds_emb, d_dposes, d_out_view, d_cost_partial,
                     d_E2, d_eval, d_best, d_A, d_s2sh, d_Ds, d_delta_s, d_fail, d_flags, d_k4tasks, d_X, d_ib_iblock, d_ib_dblock};
     for (void *p : ptrs)
         if (p && !in_arena(p)) (void)hipFree(p);
@@ -997,7 +997,7 @@ private:
             hipLaunchKernelGGL(k_backsubst_cost_step, dim3((h->V + 3) / 4), dim3(BSC_THREADS), bsc_lds, h->stream, h->d_Z,
                                h->d_Linv, h->d_Dv, h->d_gv, h->d_cam_of_view, poses_cur, poses_nxt,
                                keep_dposes ? h->d_dposes : (double *)nullptr, h->d_out_view, h->V,
-                               h->d_view_off, h->d_point_id, h->d_obs_x, h->d_obs_y, h->d_cost_view, f);
+                               h->d_view_off, h->d_point_id, h->d_obs_x, h->d_obs_y, f);
             CVX_HIP(hipGetLastError());
         }
         ph_end(h, PH_BACKSUBST);
@@ -1008,10 +1008,10 @@ private:
         const double fseq = (double)seq;
         ph_begin(h, PH_COST);
         if (spec) {
-            hipLaunchKernelGGL(k_final_scalars_decide, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V, h->d_out_view, h->V,
+            hipLaunchKernelGGL(k_final_scalars_decide, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, 0, h->d_out_view, h->V,
                                h->d_E2, h->d_E2_map + 32 * (seq & 1), fseq, h->d_lm);
         } else {
-            hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_view, h->V,
+            hipLaunchKernelGGL(k_final_scalars, dim3(1), dim3(1024), 0, h->stream, h->d_cost_partial, 0,
                                h->d_out_view, h->V, h->d_E2, (polled && !sharded_dev) ? h->d_E2_map : (double *)nullptr, fseq);
         }
         CVX_HIP(hipGetLastError());
@@ -1396,10 +1396,9 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     pc.mark("alloc_exchange");
     CVX_TRY(h->dalloc(&h->d_ds_emb, (size_t)C * h->ZC));
     CVX_TRY(h->dalloc(&h->d_dposes, 6 * (size_t)V));
-    CVX_TRY(h->dalloc(&h->d_out_view, 3 * (size_t)V));
+    CVX_TRY(h->dalloc(&h->d_out_view, 4 * (size_t)std::max(V, 1)));       // {cost, model terms} per view (step_kernels.h)
     h->n_cost_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (h->N + 255) / 256));
     CVX_TRY(h->dalloc(&h->d_cost_partial, (size_t)h->n_cost_blocks));
-    CVX_TRY(h->dalloc(&h->d_cost_view, (size_t)std::max(h->V, 1)));
     CVX_HIP(hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
     CVX_TRY(h->dalloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));

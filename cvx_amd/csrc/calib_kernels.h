@@ -1482,30 +1482,31 @@ __global__ void __launch_bounds__(256) k_assemble(AsmArgs a) {
 
 // -----------------------------------------------------------------------------------------
 // final scalar reduction (single block of 1024, fixed order):
-//   E2 = { sum cost partials, sum out_view[0][.], sum out_view[1][.], sum out_view[2][.] }
-// each thread sums a strided slice of each array
+//   E2 = { sum cost partials + sum view4[.][0], sum view4[.][1], sum view4[.][2], sum view4[.][3] }
+// cost_partial[n_partial]: the blocks of k_cost (the initial cost; n_partial = 0 in a step); view4[V][4]: what
+// k_backsubst_cost_step leaves per view = {candidate cost, dp^T (D dp - g), |dp|^2, |pose|^2} (V = 0 at the start).
+// A single workgroup is bound by the latency of its loads, so all of them are in flight at once: a thread takes every
+// 1024th view, two 16-byte loads each, FS_PER views per round (one round up to 10 240 views).
 // -----------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict__ cost_partial, int n_partial,
-                                                        const double *__restrict__ out_view, int V,
-                                                        double *__restrict__ E2, double *__restrict__ host_copy,
-                                                        double seq) {
-    __shared__ double sh[4][16];
-    // the four arrays side by side, 32 loads in flight per thread and round (a single workgroup is bound by the
-    // latency of its loads: one array after the other, with a sequential remainder loop each, took twice as long)
+constexpr int FS_PER = 10;
+__device__ __forceinline__ void final_sums(const double *__restrict__ cost_partial, int n_partial,
+                                           const double *__restrict__ view4, int V, double (*sh)[16]) {
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    const int nmax = n_partial > V ? n_partial : V;
-    for (int base = 0; base < nmax; base += 8 * 1024) {
-        double v[4][8];
+    for (int i = threadIdx.x; i < n_partial; i += 1024) s[0] += cost_partial[i];
+    for (int base = 0; base < V; base += FS_PER * 1024) {
+        double2 a[FS_PER], b[FS_PER];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < FS_PER; ++u) {
             const int i = base + (int)threadIdx.x + u * 1024;
-            v[0][u] = i < n_partial ? cost_partial[i] : 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[k + 1][u] = i < V ? out_view[(size_t)k * V + i] : 0.0;
+            const double2 *p = reinterpret_cast<const double2 *>(view4 + 4 * (size_t)(i < V ? i : 0));   // unconditional loads
+            a[u] = p[0]; b[u] = p[1];
+            if (i >= V) { a[u].x = 0.0; a[u].y = 0.0; b[u].x = 0.0; b[u].y = 0.0; }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            s[k] += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
+        static_assert(FS_PER == 10, "the sums below are written out for ten");
+        s[0] += (((a[0].x + a[1].x) + (a[2].x + a[3].x)) + ((a[4].x + a[5].x) + (a[6].x + a[7].x))) + (a[8].x + a[9].x);
+        s[1] += (((a[0].y + a[1].y) + (a[2].y + a[3].y)) + ((a[4].y + a[5].y) + (a[6].y + a[7].y))) + (a[8].y + a[9].y);
+        s[2] += (((b[0].x + b[1].x) + (b[2].x + b[3].x)) + ((b[4].x + b[5].x) + (b[6].x + b[7].x))) + (b[8].x + b[9].x);
+        s[3] += (((b[0].y + b[1].y) + (b[2].y + b[3].y)) + ((b[4].y + b[5].y) + (b[6].y + b[7].y))) + (b[8].y + b[9].y);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1514,16 +1515,27 @@ __global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict
         for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
         if (lane == 0) sh[k][wave] = s[k];
     }
+}
+// one of the four sums from its sixteen wave partials
+__device__ __forceinline__ double final_sum16(const double *q) {
+    return (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+           (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+}
+
+__global__ void __launch_bounds__(1024) k_final_scalars(const double *__restrict__ cost_partial, int n_partial,
+                                                        const double *__restrict__ view4, int V,
+                                                        double *__restrict__ E2, double *__restrict__ host_copy,
+                                                        double seq) {
+    __shared__ double sh[4][16];
+    // the step's other scalars, left in E2 by workgroup 0 of k_backsubst_cost_step (or k_step_finish): fetched now, used last
+    const double e2 = (threadIdx.x >= 4 && threadIdx.x < 16) ? E2[threadIdx.x] : 0.0;
+    final_sums(cost_partial, n_partial, view4, V, sh);
     __syncthreads();
     if (threadIdx.x < 16) {
-        double v;
+        double v = e2;
         if (threadIdx.x < 4) {
-            const double *q = sh[threadIdx.x];
-            v = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
-                (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+            v = final_sum16(sh[threadIdx.x]);
             E2[threadIdx.x] = v;
-        } else {
-            v = E2[threadIdx.x];              // the step's scalars, left there by workgroup 0 of k_backsubst_cost_step (or k_step_finish)
         }
         // single-rank runs: the 16 doubles go straight into host-mapped memory, then a sequence number the host
         // polls for (no copy kernel, no interrupt); the first wave holds all 16 writers, so no block barrier
@@ -1557,7 +1569,7 @@ __global__ void __launch_bounds__(64) k_publish_scalars(const double *__restrict
 // solve not stopped, iterations left.  The 16 doubles go to the host as k_final_scalars sends them, R[15] = 1 when the
 // kernels enqueued behind this one will run.
 __global__ void __launch_bounds__(1024) k_final_scalars_decide(const double *__restrict__ cost_partial, int n_partial,
-                                                               const double *__restrict__ out_view, int V,
+                                                               const double *__restrict__ view4, int V,
                                                                double *__restrict__ E2, double *__restrict__ host_copy,
                                                                double seq, LmDev *__restrict__ st) {
     if (!as_uniform(st)->active) {
@@ -1566,38 +1578,14 @@ __global__ void __launch_bounds__(1024) k_final_scalars_decide(const double *__r
     }
     __shared__ double sh[4][16];
     __shared__ double rec[20];
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    const int nmax = n_partial > V ? n_partial : V;
-    for (int base = 0; base < nmax; base += 8 * 1024) {
-        double v[4][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + (int)threadIdx.x + u * 1024;
-            v[0][u] = i < n_partial ? cost_partial[i] : 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[k + 1][u] = i < V ? out_view[(size_t)k * V + i] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            s[k] += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
-        if (lane == 0) sh[k][wave] = s[k];
-    }
+    const double e2 = (threadIdx.x >= 4 && threadIdx.x < 16) ? E2[threadIdx.x] : 0.0;
+    final_sums(cost_partial, n_partial, view4, V, sh);
     __syncthreads();
     if (threadIdx.x < 16) {
-        double v;
+        double v = e2;
         if (threadIdx.x < 4) {
-            const double *q = sh[threadIdx.x];
-            v = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
-                (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+            v = final_sum16(sh[threadIdx.x]);
             E2[threadIdx.x] = v;
-        } else {
-            v = E2[threadIdx.x];
         }
         rec[threadIdx.x] = v;
     }

@@ -1,8 +1,9 @@
 // K6 + K4 of an LM linear step, one wave per view, with the step's bookkeeping folded in.
 //   K6  t = Z_v * ds_emb[cam]  (the step embedded in Z's column order, 1 in the gradient column)  ->  dp = -L_v^-T t;
-//       candidate pose = pose + dp;  out_view[k][v] (three planes) = dp^T (D dp - g), |dp|^2, |pose|^2
+//       candidate pose = pose + dp;  out_view[v][1..3] = dp^T (D dp - g), |dp|^2, |pose|^2
 //   K4  the candidate's cost over the view's own observations, with the candidate rotation held in registers (same
-//       expressions as k_pose_prepare, so the value equals what k_cost computes from the tables): cost_view[v]
+//       expressions as k_pose_prepare, so the value equals what k_cost computes from the tables): out_view[v][0]
+//       (one record of four doubles per view: the final sums read it as two 16-byte loads)
 // What a one-workgroup k_step_finish (solve_kernels.h) used to make in front of this kernel -- ds_emb, the candidate
 // intrinsics and points -- is a handful of adds on the solution x of the reduced system, so every wave makes what it
 // needs from x itself (same single additions: same values), and workgroup 0 does the rest of k_step_finish's work on
@@ -40,8 +41,7 @@ __global__ void __launch_bounds__(BSC_THREADS, 5) k_backsubst_cost_step(const do
                                                                      double *__restrict__ dposes, double *__restrict__ out_view, int V,
                                                                      const int *__restrict__ view_off,
                                                                      const int *__restrict__ point_id, const double *__restrict__ obs_x,
-                                                                     const double *__restrict__ obs_y,
-                                                                     double *__restrict__ cost_view, cvxs::FinishArgs f) {
+                                                                     const double *__restrict__ obs_y, cvxs::FinishArgs f) {
     extern __shared__ double sm[];
     if (f.st) {
         // a speculated step: which buffer is current is the record's to say (uniform loads: the whole grid agrees)
@@ -115,9 +115,9 @@ __global__ void __launch_bounds__(BSC_THREADS, 5) k_backsubst_cost_step(const do
             poses_cand[6 * v + i] = pc[i];
             if (dposes) dposes[6 * v + i] = -xp[i];
         }
-        out_view[v] = m;
-        out_view[V + v] = s2;
-        out_view[2 * (size_t)V + v] = x2;
+        out_view[4 * (size_t)v + 1] = m;
+        out_view[4 * (size_t)v + 2] = s2;
+        out_view[4 * (size_t)v + 3] = x2;
     }
     // rotation of the candidate pose: the R part of k_pose_prepare, in registers
     double rtl[RT_STRIDE];
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(BSC_THREADS, 5) k_backsubst_cost_step(const do
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) cost_view[v] = acc;
+    if (lane == 0) out_view[4 * (size_t)v] = acc;
 }
 
 }  // namespace cvxk
