@@ -76,6 +76,11 @@ class ToolBADesc(C.Structure):
                 ("device", C.c_int), ("stream", C.c_void_p)]
 
 
+class RansacParams(C.Structure):
+    """cvx_ransac_params = cvx::util::RANSAC::Parameters (ransac.hpp:12-23)"""
+    _fields_ = [("max_error", C.c_double), ("outlier_probability", C.c_double), ("max_num_trials", C.c_int), ("min_inliers", C.c_int)]
+
+
 class Damping(C.Structure):
     _fields_ = [("inv_radius", C.c_double), ("mu", C.c_double), ("min_diag", C.c_double), ("max_diag", C.c_double)]
 
@@ -155,6 +160,9 @@ SIGNATURES = {
     "cvx_homography_get": (C.c_int, [C.c_void_p, dp, dp, ip]),
     "cvx_homography_dlt": (C.c_int, [C.c_void_p, dp]),
     "cvx_homography_residuals": (C.c_int, [C.c_void_p, dp, dp]),
+    "cvx_ransac_default_params": (None, [C.POINTER(RansacParams)]),
+    "cvx_homography_ransac": (C.c_int, [C.c_void_p, C.POINTER(RansacParams), ip, C.c_ulonglong, dp, ip,
+                                        C.POINTER(C.c_ubyte), ip, ip, C.POINTER(C.c_void_p)]),
     "cvx_calib_data_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "cvx_calib_data_free": (None, [C.c_void_p]),
     "cvx_calib_data_info": (C.c_int, [C.c_void_p, ip, ip, ip, ip, C.POINTER(C.c_int64)]),

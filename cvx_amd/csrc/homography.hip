@@ -2,6 +2,7 @@
 // Replaces HomographyEstimator::solveLM (/root/reference/modules/calib/src/homography.cpp:218-236) for many
 // independent views at once.
 #include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -13,7 +14,9 @@ using namespace cvxhom;
 
 struct cvx_homography {
     int n = 0, device = 0, max_points = 0;
-    long long total = 0;
+    long long total = 0;             // point pairs in use
+    size_t tp = 1;                   // stride of the four coordinate planes in d_pts (>= total: a batch built on the device
+                                     // -- the inliers of cvx_homography_ransac -- is sized before its total is known)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int *d_off = nullptr, *d_ret = nullptr;
@@ -29,6 +32,33 @@ struct cvx_homography {
         if (own_stream) cvx::own_stream_end(device, stream);
     }
 };
+
+// a handle with room for `capacity` point pairs; nothing uploaded, H zeroed
+static int make_handle(int n_problems, long long capacity, int max_points, int device, void *stream, cvx_homography **out) {
+    std::unique_ptr<cvx_homography> h(new cvx_homography);
+    h->n = n_problems; h->device = device; h->max_points = max_points; h->total = capacity;
+    if (stream) h->stream = (hipStream_t)stream;
+    else { h->own_stream = true; const int sst = cvx::own_stream_begin(h->device, &h->stream); if (sst) return sst; }
+    h->lds_bytes = hom_lds_doubles(max_points < 4 ? 4 : max_points) * sizeof(double);
+    const size_t tp = (size_t)(capacity > 0 ? capacity : 1);
+    h->tp = tp;
+    {
+        // one device block, carved on 256-byte boundaries: points | H | info | offsets | return values
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t b_pts = up(sizeof(float) * 4 * tp), b_H = up(sizeof(double) * 9 * n_problems), b_info = up(sizeof(double) * 10 * n_problems),
+                     b_off = up(sizeof(int) * ((size_t)n_problems + 1)), b_ret = up(sizeof(int) * (size_t)n_problems);
+        char *base = nullptr;
+        CVX_HIP(hipMalloc((void **)&base, b_pts + b_H + b_info + b_off + b_ret));
+        h->d_pts = reinterpret_cast<float *>(base); base += b_pts;
+        h->d_H = reinterpret_cast<double *>(base); base += b_H;
+        h->d_info = reinterpret_cast<double *>(base); base += b_info;
+        h->d_off = reinterpret_cast<int *>(base); base += b_off;
+        h->d_ret = reinterpret_cast<int *>(base);
+    }
+    CVX_HIP(hipMemsetAsync(h->d_H, 0, sizeof(double) * 9 * n_problems, h->stream));
+    *out = h.release();
+    return CVX_OK;
+}
 
 extern "C" int cvx_homography_create(int n_problems, const int *off, const float *x1, const float *y1,
                                      const float *x2, const float *y2, int device, void *stream,
@@ -51,26 +81,11 @@ extern "C" int cvx_homography_create(int n_problems, const int *off, const float
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { cvx::set_last_error("no HIP device"); return CVX_ERR_NO_DEVICE; }
     CVX_HIP(hipSetDevice(device));
-    std::unique_ptr<cvx_homography> h(new cvx_homography);
-    h->n = n_problems; h->device = device; h->max_points = max_points; h->total = total;
-    if (stream) h->stream = (hipStream_t)stream;
-    else { h->own_stream = true; const int sst = cvx::own_stream_begin(h->device, &h->stream); if (sst) return sst; }
-    h->lds_bytes = hom_lds_doubles(max_points < 4 ? 4 : max_points) * sizeof(double);
-    const size_t tp = (size_t)(total > 0 ? total : 1);
-    {
-        // one device block, carved on 256-byte boundaries: points | H | info | offsets | return values
-        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-        const size_t b_pts = up(sizeof(float) * 4 * tp), b_H = up(sizeof(double) * 9 * n_problems), b_info = up(sizeof(double) * 10 * n_problems),
-                     b_off = up(sizeof(int) * ((size_t)n_problems + 1)), b_ret = up(sizeof(int) * (size_t)n_problems);
-        char *base = nullptr;
-        CVX_HIP(hipMalloc((void **)&base, b_pts + b_H + b_info + b_off + b_ret));
-        h->d_pts = reinterpret_cast<float *>(base); base += b_pts;
-        h->d_H = reinterpret_cast<double *>(base); base += b_H;
-        h->d_info = reinterpret_cast<double *>(base); base += b_info;
-        h->d_off = reinterpret_cast<int *>(base); base += b_off;
-        h->d_ret = reinterpret_cast<int *>(base);
-    }
-    CVX_HIP(hipMemsetAsync(h->d_H, 0, sizeof(double) * 9 * n_problems, h->stream));
+    cvx_homography *raw = nullptr;
+    const int mst = make_handle(n_problems, total, max_points, device, stream, &raw);
+    if (mst) return mst;
+    std::unique_ptr<cvx_homography> h(raw);
+    const size_t tp = h->tp;
     CVX_HIP(hipMemcpyAsync(h->d_off, off, sizeof(int) * (n_problems + 1), hipMemcpyHostToDevice, h->stream));
     if (total > 0) {
         const float *src[4] = {x1, y1, x2, y2};
@@ -96,7 +111,7 @@ extern "C" int cvx_homography_set(cvx_homography *h, const double *H) {
 extern "C" int cvx_homography_run(cvx_homography *h, int max_iter, const double *opts) {
     if (!h || max_iter < 0) return CVX_ERR_INVALID_ARG;
     CVX_HIP(hipSetDevice(h->device));
-    const size_t tp = (size_t)(h->total > 0 ? h->total : 1);
+    const size_t tp = h->tp;
     HomArgs a;
     a.off = h->d_off;
     a.x1 = h->d_pts; a.y1 = h->d_pts + tp; a.x2 = h->d_pts + 2 * tp; a.y2 = h->d_pts + 3 * tp;
@@ -149,7 +164,7 @@ extern "C" int cvx_homography_solve(cvx_homography *h, double *H, int max_iter, 
 }
 
 static DltArgs dlt_args(cvx_homography *h) {
-    const size_t tp = (size_t)(h->total > 0 ? h->total : 1);
+    const size_t tp = h->tp;
     DltArgs a;
     a.off = h->d_off;
     a.x1 = h->d_pts; a.y1 = h->d_pts + tp; a.x2 = h->d_pts + 2 * tp; a.y2 = h->d_pts + 3 * tp;
@@ -159,20 +174,26 @@ static DltArgs dlt_args(cvx_homography *h) {
 
 // HomographyEstimator::solve (homography.cpp:46-93) for every problem of the handle; the estimates stay on the device
 // as the start of cvx_homography_run
-extern "C" int cvx_homography_dlt(cvx_homography *h, double *H) {
-    if (!h) return CVX_ERR_INVALID_ARG;
-    CVX_HIP(hipSetDevice(h->device));
-    if (!h->d_W) CVX_HIP(hipMalloc(&h->d_W, sizeof(double) * DLT_W * h->n));
-    const DltArgs a = dlt_args(h);
-    const size_t lds = dlt_lds_doubles(h->max_points < 4 ? 4 : h->max_points) * sizeof(double);
+// the two launches of the normalised DLT over a batch described by `a`, no problem larger than max_points
+static int launch_dlt(const DltArgs &a, int max_points, hipStream_t stream) {
+    const size_t lds = dlt_lds_doubles(max_points < 4 ? 4 : max_points) * sizeof(double);
     CVX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_homography_dlt_reduce),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CVX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_homography_dlt_finish),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DLT_FIN_LDS));
-    hipLaunchKernelGGL(k_homography_dlt_reduce, dim3(h->n), dim3(64), lds, h->stream, a);
-    hipLaunchKernelGGL(k_homography_dlt_finish, dim3((h->n + DLT_FIN_THREADS - 1) / DLT_FIN_THREADS), dim3(DLT_FIN_THREADS),
-                       DLT_FIN_LDS, h->stream, a);
+    hipLaunchKernelGGL(k_homography_dlt_reduce, dim3(a.n_problems), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL(k_homography_dlt_finish, dim3((a.n_problems + DLT_FIN_THREADS - 1) / DLT_FIN_THREADS), dim3(DLT_FIN_THREADS),
+                       DLT_FIN_LDS, stream, a);
     CVX_HIP(hipGetLastError());
+    return CVX_OK;
+}
+
+extern "C" int cvx_homography_dlt(cvx_homography *h, double *H) {
+    if (!h) return CVX_ERR_INVALID_ARG;
+    CVX_HIP(hipSetDevice(h->device));
+    if (!h->d_W) CVX_HIP(hipMalloc(&h->d_W, sizeof(double) * DLT_W * h->n));
+    const int lst = launch_dlt(dlt_args(h), h->max_points, h->stream);
+    if (lst) return lst;
     if (H) CVX_HIP(hipMemcpyAsync(H, h->d_H, sizeof(double) * 9 * h->n, hipMemcpyDeviceToHost, h->stream));
     CVX_HIP(hipStreamSynchronize(h->stream));
     return CVX_OK;
@@ -191,3 +212,111 @@ extern "C" int cvx_homography_residuals(cvx_homography *h, const double *H, doub
     CVX_HIP(hipStreamSynchronize(h->stream));
     return CVX_OK;
 }
+
+extern "C" void cvx_ransac_default_params(cvx_ransac_params *p) {
+    if (!p) return;
+    p->max_error = 0.1; p->outlier_probability = 0.1; p->max_num_trials = 100; p->min_inliers = 5;     // ransac.hpp:14-22
+}
+
+// HomographyEstimator::solveRansac (homography.cpp:151-156) for every problem of the handle: homography_kernels.h
+extern "C" int cvx_homography_ransac(cvx_homography *h, const cvx_ransac_params *params, const int *subsets,
+                                     unsigned long long seed, double *H, int *n_inliers, unsigned char *inlier_mask,
+                                     int *trials_run, int *subsets_used, cvx_homography **inlier_batch) {
+    if (inlier_batch) *inlier_batch = nullptr;
+    if (!h) return CVX_ERR_INVALID_ARG;
+    cvx_ransac_params p;
+    cvx_ransac_default_params(&p);
+    if (params) p = *params;
+    if (p.max_num_trials < 1 || p.min_inliers < 0 || !(p.outlier_probability >= 0.0 && p.outlier_probability < 1.0) || !(p.max_error == p.max_error)) {
+        cvx::set_last_error("ransac: max_num_trials >= 1, min_inliers >= 0, 0 <= outlier_probability < 1");
+        return CVX_ERR_INVALID_ARG;
+    }
+    const long long M = (long long)h->n * p.max_num_trials;
+    if (M > CVX_RANSAC_MAX_HYPOTHESES) {
+        cvx::set_last_error("ransac: problems x max_num_trials beyond CVX_RANSAC_MAX_HYPOTHESES (run the batch in parts)");
+        return CVX_ERR_UNSUPPORTED;
+    }
+    CVX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t n = (size_t)h->n, Mz = (size_t)M, tot = (size_t)(h->total > 0 ? h->total : 1);
+    // the refit batch: room for every pair (its total is known only after the selection)
+    cvx_homography *raw = nullptr;
+    // (on the caller's stream if the source handle runs on one, else on a stream of its own: it may outlive the source)
+    int st = make_handle(h->n, h->total, h->max_points, h->device, h->own_stream ? nullptr : (void *)h->stream, &raw);
+    if (st) return st;
+    std::unique_ptr<cvx_homography> nb(raw);
+    if (nb->stream != s) CVX_HIP(hipStreamSynchronize(nb->stream));      // its zeroed estimates, before this stream writes them
+    CVX_HIP(hipMemcpyAsync(nb->d_H, h->d_H, sizeof(double) * 9 * n, hipMemcpyDeviceToDevice, s));      // no model: the estimate stays
+    CVX_HIP(hipMalloc(&nb->d_W, sizeof(double) * DLT_W * n));
+    // everything of the hypothesis batch in one block
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_off = up(sizeof(int) * (Mz + 1)), b_pts = up(sizeof(float) * 16 * Mz), b_W = up(sizeof(double) * DLT_W * Mz),
+                 b_H = up(sizeof(double) * 9 * Mz), b_cnt = up(sizeof(int) * Mz), b_mean = up(sizeof(double) * Mz),
+                 b_sub = up(sizeof(int) * 4 * Mz), b_per = up(sizeof(int) * n), b_mask = up(tot), b_flags = 256;
+    char *block = nullptr;
+    CVX_HIP(hipMalloc((void **)&block, b_off + b_pts + b_W + b_H + b_cnt + b_mean + 2 * b_sub + 3 * b_per + b_mask + b_flags));
+    struct Free { char *p; ~Free() { if (p) (void)hipFree(p); } } guard{block};
+    char *q = block;
+    RansacArgs a;
+    a.off = h->d_off;
+    a.x1 = h->d_pts; a.y1 = h->d_pts + h->tp; a.x2 = h->d_pts + 2 * h->tp; a.y2 = h->d_pts + 3 * h->tp;
+    a.n_problems = h->n; a.T = p.max_num_trials;
+    a.seed = seed;
+    a.max_error = p.max_error; a.log_probability = std::log(1.0 - p.outlier_probability); a.min_inliers = p.min_inliers;
+    a.hyp_off = reinterpret_cast<int *>(q); q += b_off;
+    a.hx1 = reinterpret_cast<float *>(q); a.hy1 = a.hx1 + 4 * Mz; a.hx2 = a.hx1 + 8 * Mz; a.hy2 = a.hx1 + 12 * Mz; q += b_pts;
+    double *hyp_W = reinterpret_cast<double *>(q); q += b_W;
+    double *hyp_H = reinterpret_cast<double *>(q); q += b_H;
+    a.hyp_H = hyp_H;
+    a.cnt = reinterpret_cast<int *>(q); q += b_cnt;
+    a.mean = reinterpret_cast<double *>(q); q += b_mean;
+    int *d_subsets = reinterpret_cast<int *>(q); q += b_sub;
+    a.subsets_used = reinterpret_cast<int *>(q); q += b_sub;
+    a.best = reinterpret_cast<int *>(q); q += b_per;
+    a.trials_run = reinterpret_cast<int *>(q); q += b_per;
+    a.n_inl = reinterpret_cast<int *>(q); q += b_per;
+    a.mask = reinterpret_cast<unsigned char *>(q); q += b_mask;
+    a.flags = reinterpret_cast<int *>(q);
+    a.subsets = nullptr;
+    if (subsets) {
+        CVX_HIP(hipMemcpyAsync(d_subsets, subsets, sizeof(int) * 4 * Mz, hipMemcpyHostToDevice, s));
+        a.subsets = d_subsets;
+    }
+    if (!subsets_used) a.subsets_used = nullptr;
+    a.new_off = nb->d_off;
+    a.nx1 = nb->d_pts; a.ny1 = nb->d_pts + nb->tp; a.nx2 = nb->d_pts + 2 * nb->tp; a.ny2 = nb->d_pts + 3 * nb->tp;
+    CVX_HIP(hipMemsetAsync(a.flags, 0, sizeof(int), s));
+    CVX_HIP(hipMemsetAsync(a.mask, 0, tot, s));
+    CVX_HIP(hipMemsetAsync(hyp_H, 0, sizeof(double) * 9 * Mz, s));
+    hipLaunchKernelGGL(k_hom_ransac_gather, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, s, a);
+    CVX_HIP(hipGetLastError());
+    DltArgs d;
+    d.off = a.hyp_off; d.x1 = a.hx1; d.y1 = a.hy1; d.x2 = a.hx2; d.y2 = a.hy2; d.W = hyp_W; d.H = hyp_H; d.n_problems = (int)M;
+    st = launch_dlt(d, 4, s);
+    if (st) return st;
+    hipLaunchKernelGGL(k_hom_ransac_score, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_hom_ransac_select, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_hom_ransac_offsets, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_hom_ransac_compact, dim3(h->n), dim3(64), 0, s, a);
+    CVX_HIP(hipGetLastError());
+    // the model of the best trial's inliers (ransac.hpp:77)
+    st = launch_dlt(dlt_args(nb.get()), nb->max_points, s);
+    if (st) return st;
+    int flag = 0;
+    std::vector<int> counts(n);
+    CVX_HIP(hipMemcpyAsync(&flag, a.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    CVX_HIP(hipMemcpyAsync(counts.data(), a.n_inl, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+    if (H) CVX_HIP(hipMemcpyAsync(H, nb->d_H, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, s));
+    if (inlier_mask && h->total > 0) CVX_HIP(hipMemcpyAsync(inlier_mask, a.mask, (size_t)h->total, hipMemcpyDeviceToHost, s));
+    if (trials_run) CVX_HIP(hipMemcpyAsync(trials_run, a.trials_run, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+    if (subsets_used) CVX_HIP(hipMemcpyAsync(subsets_used, a.subsets_used, sizeof(int) * 4 * Mz, hipMemcpyDeviceToHost, s));
+    CVX_HIP(hipStreamSynchronize(s));
+    if (flag) { cvx::set_last_error("ransac: a subset names a pair outside its problem, or the same pair twice"); return CVX_ERR_INVALID_ARG; }
+    long long used = 0;
+    for (size_t i = 0; i < n; ++i) used += counts[i];
+    nb->total = used;
+    if (n_inliers) std::memcpy(n_inliers, counts.data(), sizeof(int) * n);
+    if (inlier_batch) *inlier_batch = nb.release();
+    return CVX_OK;
+}
+

@@ -623,4 +623,201 @@ __global__ __launch_bounds__(64) void k_homography_residuals(DltArgs a, double *
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// HomographyEstimator::solveRansac (/root/reference/modules/calib/src/homography.cpp:112-156) = cvx::util::RANSAC::estimate
+// (modules/util/include/cvx/util/math/ransac.hpp:28-78) with the minimal model of four pairs, for every problem of a
+// batch.  A trial's outcome -- its model, its inliers, their mean residual -- does not depend on the trials before it; only
+// the loop's bookkeeping does (the best so far, and max_trials, which the first acceptable model usually cuts to a
+// handful).  So all max_num_trials hypotheses of all problems are fitted and scored at once, and one lane per problem
+// then walks the trials in order exactly as the loop would, stopping where it would:
+//   k_hom_ransac_gather    the four pairs of every hypothesis, from the caller's subsets (what RNG::sample draws, rng.hpp:62-75)
+//                          or drawn here from a seed (a counter-based generator: the reference seeds std::mt19937_64 from
+//                          std::random_device, rng.cpp:6-9, so there is no sequence of its own to reproduce)
+//   k_homography_dlt_*     the models (the batch of four-pair problems is an ordinary DLT batch)
+//   k_hom_ransac_score     findInliers (homography.cpp:131-144): one lane per hypothesis, the residuals added in index order
+//   k_hom_ransac_select    the loop of ransac.hpp:44-73 on the scores
+//   k_hom_ransac_offsets   where each problem's inliers go in the refit batch (exclusive scan)
+//   k_hom_ransac_compact   best_subset, in index order, as a new batch; the refit (:77) is a DLT on that batch
+// -----------------------------------------------------------------------------------------
+struct RansacArgs {
+    const int *off;
+    const float *x1, *y1, *x2, *y2;
+    int n_problems, T;                       // T = max_num_trials
+    const int *subsets;                      // [n_problems][T][4] or null
+    unsigned long long seed;
+    double max_error, log_probability;
+    int min_inliers;
+    int *hyp_off;                            // [M + 1], M = n_problems * T
+    float *hx1, *hy1, *hx2, *hy2;            // [4 M]
+    int *subsets_used;                       // [M][4]
+    const double *hyp_H;                     // [M][9]
+    int *cnt;                                // [M]
+    double *mean;                            // [M]
+    int *best, *trials_run, *n_inl;          // [n_problems]
+    int *flags;                              // [0]: a subset index out of range or repeated
+    // the refit batch
+    int *new_off;                            // [n_problems + 1]
+    float *nx1, *ny1, *nx2, *ny2;
+    unsigned char *mask;                     // [total] (zeroed by the caller)
+};
+
+__device__ __forceinline__ unsigned long long hom_mix64(unsigned long long z) {      // splitmix64's output function
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_hom_ransac_gather(RansacArgs a) {
+    const long long M = (long long)a.n_problems * a.T;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m > M) return;
+    if (m == M) { a.hyp_off[M] = (int)(4 * M); return; }
+    a.hyp_off[m] = (int)(4 * m);
+    const int prob = (int)(m / a.T);
+    const int o0 = a.off[prob], N = a.off[prob + 1] - o0;
+    int sub[4] = {0, 0, 0, 0};
+    bool ok = N >= 4;
+    if (ok && a.subsets) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sub[k] = a.subsets[4 * m + k];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bad = bad || sub[k] < 0 || sub[k] >= N;
+#pragma unroll
+            for (int j = 0; j < k; ++j) bad = bad || sub[j] == sub[k];
+        }
+        if (bad) { a.flags[0] = 1; ok = false; }
+    } else if (ok) {
+        // RNG::sample's swaps (rng.hpp:66-74) on an index vector that is never made: the few entries a draw has moved
+        int pos[8], val[8], nm = 0;
+        auto get = [&](int i) { int v = i; for (int j = 0; j < nm; ++j) if (pos[j] == i) v = val[j]; return v; };
+        auto set = [&](int i, int v) {
+            for (int j = 0; j < nm; ++j) if (pos[j] == i) { val[j] = v; return; }
+            pos[nm] = i; val[nm] = v; ++nm;
+        };
+        for (int k = 0; k < 4; ++k) {
+            const int max_idx = N - 1 - k;
+            const unsigned long long r = hom_mix64(a.seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(4 * m + k + 1));
+            const int index = (int)__umul64hi(r, (unsigned long long)(max_idx + 1));       // uniform on [0, max_idx]
+            const int vi = get(index), vm = get(max_idx);
+            set(index, vm); set(max_idx, vi);
+            sub[k] = vi;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = o0 + sub[k];
+        a.hx1[4 * m + k] = ok ? a.x1[i] : 0.f; a.hy1[4 * m + k] = ok ? a.y1[i] : 0.f;
+        a.hx2[4 * m + k] = ok ? a.x2[i] : 0.f; a.hy2[4 * m + k] = ok ? a.y2[i] : 0.f;
+        if (a.subsets_used) a.subsets_used[4 * m + k] = ok ? sub[k] : -1;
+    }
+}
+
+// the residual of homography.cpp:105-108 for one pair
+__device__ __forceinline__ double hom_transfer_residual(const double H[9], const double Hi[9], double x, double y, double z, double w) {
+    const double w1 = H[6] * x + H[7] * y + H[8], w2 = Hi[6] * z + Hi[7] * w + Hi[8];
+    const double e0 = (H[0] * x + H[1] * y + H[2]) / w1 - z, e1 = (H[3] * x + H[4] * y + H[5]) / w1 - w;
+    const double f0 = (Hi[0] * z + Hi[1] * w + Hi[2]) / w2 - x, f1 = (Hi[3] * z + Hi[4] * w + Hi[5]) / w2 - y;
+    return sqrt(e0 * e0 + e1 * e1) + sqrt(f0 * f0 + f1 * f1);
+}
+
+__global__ __launch_bounds__(256) void k_hom_ransac_score(RansacArgs a) {
+    const long long M = (long long)a.n_problems * a.T;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int prob = (int)(m / a.T);
+    const int o0 = a.off[prob], N = a.off[prob + 1] - o0;
+    int cnt = 0;
+    double total = 0.0;
+    if (N >= 4) {
+        double H[9], Hi[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H[i] = a.hyp_H[9 * m + i];
+        hom_inverse3(H, Hi);
+        for (int i = 0; i < N; ++i) {       // (a wave's lanes belong to one or two problems: the loads are broadcasts)
+            const double r = hom_transfer_residual(H, Hi, a.x1[o0 + i], a.y1[o0 + i], a.x2[o0 + i], a.y2[o0 + i]);
+            if (r < a.max_error) { ++cnt; total += r; }
+        }
+    }
+    a.cnt[m] = cnt;
+    a.mean[m] = total / (double)cnt;        // 0 / 0 with no inlier, as the reference (:142); never used then (ransac.hpp:55)
+}
+
+__global__ __launch_bounds__(256) void k_hom_ransac_select(RansacArgs a) {
+    const int prob = blockIdx.x * 256 + threadIdx.x;
+    if (prob >= a.n_problems) return;
+    const int N = a.off[prob + 1] - a.off[prob];
+    int best = -1, nbest = 0;
+    size_t trial = 0;
+    if (N >= 4) {
+        const double one_over_indices = 1.0 / (double)N;
+        const size_t max_num = (size_t)a.T;
+        size_t max_trials = max_num;
+        double min_residual = DBL_MAX;
+        while (trial < (max_num < max_trials ? max_num : max_trials)) {
+            const long long m = (long long)prob * a.T + (long long)trial;
+            const int c = a.cnt[m];
+            const double r = a.mean[m];
+            if (c > a.min_inliers && r < min_residual) {
+                min_residual = r; best = (int)trial; nbest = c;
+                const double w = (double)c * one_over_indices;
+                double p_no_outliers = 1.0 - pow(w, 4.0);
+                p_no_outliers = p_no_outliers > DBL_EPSILON ? p_no_outliers : DBL_EPSILON;
+                p_no_outliers = p_no_outliers < 1.0 - DBL_EPSILON ? p_no_outliers : 1.0 - DBL_EPSILON;
+                max_trials = (size_t)(a.log_probability / log(p_no_outliers));
+            }
+            ++trial;
+        }
+    }
+    a.best[prob] = best; a.n_inl[prob] = nbest; a.trials_run[prob] = (int)trial;
+}
+
+// exclusive scan of n_inl (one workgroup of 1024: a contiguous run per thread, the runs' sums scanned by thread 0)
+__global__ __launch_bounds__(1024) void k_hom_ransac_offsets(RansacArgs a) {
+    __shared__ int run[1024];
+    const int n = a.n_problems, per = (n + 1023) / 1024;
+    const int i0 = min(n, (int)threadIdx.x * per), i1 = min(n, i0 + per);
+    int s = 0;
+    for (int i = i0; i < i1; ++i) s += a.n_inl[i];
+    run[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int t = 0; t < 1024; ++t) { const int v = run[t]; run[t] = acc; acc += v; }
+        a.new_off[n] = acc;
+    }
+    __syncthreads();
+    int acc = run[threadIdx.x];
+    for (int i = i0; i < i1; ++i) { a.new_off[i] = acc; acc += a.n_inl[i]; }
+}
+
+__global__ __launch_bounds__(64) void k_hom_ransac_compact(RansacArgs a) {
+    const int prob = blockIdx.x, lane = threadIdx.x;
+    const int best = a.best[prob];
+    if (best < 0) return;
+    const int o0 = a.off[prob], N = a.off[prob + 1] - o0;
+    double H[9], Hi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] = a.hyp_H[9 * ((long long)prob * a.T + best) + i];
+    hom_inverse3(H, Hi);
+    int base = a.new_off[prob];
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        float x = 0.f, y = 0.f, z = 0.f, w = 0.f;
+        bool in = false;
+        if (i < N) {
+            x = a.x1[o0 + i]; y = a.y1[o0 + i]; z = a.x2[o0 + i]; w = a.y2[o0 + i];
+            in = hom_transfer_residual(H, Hi, x, y, z, w) < a.max_error;
+            a.mask[o0 + i] = in ? 1 : 0;
+        }
+        const unsigned long long b = __ballot(in);
+        if (in) {
+            const int p = base + __popcll(b & ((1ULL << lane) - 1ULL));
+            a.nx1[p] = x; a.ny1[p] = y; a.nx2[p] = z; a.ny2[p] = w;
+        }
+        base += __popcll(b);
+    }
+}
+
 }  // namespace cvxhom

@@ -333,6 +333,40 @@ class HomographyBatch:
         return res
 
 
+    def ransac(self, subsets=None, seed=0, params=None, want_subsets=False, keep_inliers=False):
+        """HomographyEstimator::solveRansac (homography.cpp:151-156) of every problem.  subsets [n, max_num_trials, 4] = what
+        RNG::sample draws trial after trial, or None: drawn on the device from `seed`.
+        -> dict(H [n, 9], n_inliers [n], mask [total] uint8, trials_run [n], subsets (if asked), inliers = a
+        HomographyBatch of the inliers with the refit as estimates (if asked: run() on it is solveLM over the inliers))"""
+        p = capi.RansacParams()
+        lib().cvx_ransac_default_params(C.byref(p))
+        if params:
+            for k, v in params.items():
+                setattr(p, k, v)
+        T = p.max_num_trials
+        sub = None
+        if subsets is not None:
+            sub = i32(np.asarray(subsets).reshape(self.n, T, 4))
+        H = np.zeros((self.n, 9)); ni = np.zeros(self.n, np.int32); tr = np.zeros(self.n, np.int32)
+        mask = np.zeros(max(int(self.off[-1]), 1), np.uint8)
+        used = np.zeros((self.n, T, 4), np.int32) if want_subsets else None
+        nb = C.c_void_p()
+        check(lib().cvx_homography_ransac(self.h, C.byref(p), pi(sub) if sub is not None else None, int(seed), pd(H), pi(ni),
+                                          mask.ctypes.data_as(C.POINTER(C.c_ubyte)), pi(tr), pi(used) if want_subsets else None,
+                                          C.byref(nb) if keep_inliers else None), "cvx_homography_ransac")
+        out = dict(H=H, n_inliers=ni, mask=mask[:int(self.off[-1])], trials_run=tr)
+        if want_subsets:
+            out["subsets"] = used
+        if keep_inliers:
+            b = HomographyBatch.__new__(HomographyBatch)
+            b.n = self.n
+            b.off = np.concatenate([[0], np.cumsum(ni)]).astype(np.int32)
+            b.pts = None
+            b.h = nb
+            out["inliers"] = b
+        return out
+
+
 class ToolBA:
     """cvx_toolba handle: bundleAdjustment of tools/hand_eye_registration.cpp:144-238 on one GPU."""
 

@@ -401,6 +401,36 @@ int cvx_homography_dlt(cvx_homography *h, double *H);
  * the order of the point arrays (off[n_problems] doubles).  H: n_problems x 9 row-major, or NULL = the handle's current
  * estimates (what cvx_homography_dlt / _run / _set left). */
 int cvx_homography_residuals(cvx_homography *h, const double *H, double *res);
+/* HomographyEstimator::solveRansac (homography.cpp:112-156): cvx::util::RANSAC::estimate (modules/util/include/cvx/util/
+ * math/ransac.hpp:28-78) with the minimal model of four pairs (fit = solve on the subset, :119-129; findInliers = the
+ * pairs whose residual is below max_error and their mean residual, :131-144), for every problem of the handle.  A
+ * trial's outcome does not depend on the trials before it, so all max_num_trials hypotheses of all problems are fitted
+ * and scored at once, and the loop of ransac.hpp:44-73 -- keep the trial with more than min_inliers inliers and the
+ * smallest mean residual, cut max_trials to log(1 - outlier_probability) / log(1 - w^4) -- is then walked per problem
+ * over the scores, stopping where the reference's loop stops; the returned model is solve() on ALL inliers of the
+ * kept trial (:77).
+ * params: NULL = RANSAC::Parameters' defaults {0.1, 0.1, 100, 5} (what solveRansac runs on: `RANSAC solver;`, :152).
+ * subsets: [n_problems][max_num_trials][4] indices into each problem's own pairs = what RNG::sample(4, n, .) draws trial
+ * after trial (rng.hpp:62-75; the adaptor draws them with the reference's own generator type), or NULL: drawn on the
+ * device from `seed` by a counter-based generator (the reference seeds its std::mt19937_64 from std::random_device,
+ * rng.cpp:6-9: it has no sequence of its own to reproduce).
+ * Out, each may be NULL: H (n_problems x 9 row-major; a problem for which estimate() returns false keeps the handle's
+ * current estimate), n_inliers[n_problems] (0 = estimate() false), inlier_mask[off[n_problems]] (1 = in best_subset),
+ * trials_run[n_problems] (trial_count when the loop ended), subsets_used[n_problems][max_num_trials][4] (-1 for problems
+ * with fewer than 4 pairs), inlier_batch = a new handle (the caller destroys it) whose problems are the inliers in index
+ * order with the refit as current estimates: cvx_homography_run on it is solveLM(pts1, pts2, inliers, H) (:218-236).
+ * n_problems x max_num_trials beyond CVX_RANSAC_MAX_HYPOTHESES: CVX_ERR_UNSUPPORTED (704 bytes of work space each). */
+#define CVX_RANSAC_MAX_HYPOTHESES (1 << 23)
+typedef struct cvx_ransac_params {
+    double max_error;             /* 0.1 */
+    double outlier_probability;   /* 0.1 */
+    int max_num_trials;           /* 100 */
+    int min_inliers;              /* 5   */
+} cvx_ransac_params;
+void cvx_ransac_default_params(cvx_ransac_params *p);
+int cvx_homography_ransac(cvx_homography *h, const cvx_ransac_params *params, const int *subsets, unsigned long long seed,
+                          double *H, int *n_inliers, unsigned char *inlier_mask, int *trials_run, int *subsets_used,
+                          cvx_homography **inlier_batch);
 
 /* ------------------------------------------------------------------------ */
 /* On-disk formats either side of the path (host only)   */

@@ -1676,6 +1676,79 @@ void orc_homography_residuals(int n, const float *x1, const float *y1, const flo
     }
 }
 
+/* ---- HomographyEstimator::solveRansac (homography.cpp:112-156) on RANSAC::estimate (ransac.hpp:28-78) ---- */
+void orc_ransac_defaults(orc_ransac_params *p) {
+    p->max_error = 0.1; p->outlier_probability = 0.1; p->max_num_trials = 100; p->min_inliers = 5;   /* ransac.hpp:14-22 */
+}
+
+/* rng.hpp:62-75: vidx = 0 .. N-1; per draw: swap(vidx[index], vidx[max_idx]), take vidx[max_idx], --max_idx */
+void orc_rng_sample4(int N, const int draw[4], int subset[4]) {
+    int *vidx = malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
+    for (int i = 0; i < N; ++i) vidx[i] = i;
+    int max_idx = N - 1;
+    for (int k = 0; k < 4; ++k) {
+        const int index = draw[k];
+        const int t = vidx[index]; vidx[index] = vidx[max_idx]; vidx[max_idx] = t;
+        subset[k] = vidx[max_idx];
+        --max_idx;
+    }
+    free(vidx);
+}
+
+int orc_homography_ransac(int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                          const orc_ransac_params *p, const int *subsets, double H[9], int *inliers, int *n_inliers,
+                          int *trials_run) {
+    *n_inliers = 0; *trials_run = 0;
+    if (n < 4) return 0;                                   /* assert(N <= n), ransac.hpp:32 */
+    const double log_probability = log(1.0 - p->outlier_probability);            /* :34 */
+    const double one_over_indices = 1.0 / (double)n;                             /* :35 */
+    size_t trial_count = 0, max_trials = (size_t)p->max_num_trials;
+    const size_t max_num = (size_t)p->max_num_trials;
+    double min_residual = DBL_MAX;
+    double *res = malloc(sizeof(double) * (size_t)n);
+    int *cur = malloc(sizeof(int) * (size_t)n), nbest = 0;
+    float *g = malloc(sizeof(float) * 4 * (size_t)n);     /* gathered subsets: the four points of a trial, the inliers at the end */
+    while (trial_count < (max_num < max_trials ? max_num : max_trials)) {        /* :44 */
+        const int *sub = subsets + 4 * trial_count;
+        for (int k = 0; k < 4; ++k) { g[k] = x1[sub[k]]; g[n + k] = y1[sub[k]]; g[2 * n + k] = x2[sub[k]]; g[3 * n + k] = y2[sub[k]]; }
+        double Ht[9];
+        orc_homography_dlt(4, g, g + n, g + 2 * n, g + 3 * n, Ht);               /* fit(): always true (homography.cpp:119-129) */
+        /* findInliers (homography.cpp:131-144) */
+        orc_homography_residuals(n, x1, y1, x2, y2, Ht, res);
+        int cnt = 0;
+        double total = 0.0;
+        for (int i = 0; i < n; ++i)
+            if (res[i] < p->max_error) { cur[cnt++] = i; total += res[i]; }
+        total /= (double)cnt;
+        if ((size_t)cnt > (size_t)p->min_inliers) {                              /* :55 */
+            if (total < min_residual) {
+                min_residual = total;
+                memcpy(inliers, cur, sizeof(int) * (size_t)cnt);
+                nbest = cnt;
+                const double w = (double)cnt * one_over_indices;
+                double p_no_outliers = 1.0 - pow(w, 4.0);
+                p_no_outliers = p_no_outliers > DBL_EPSILON ? p_no_outliers : DBL_EPSILON;
+                p_no_outliers = p_no_outliers < 1.0 - DBL_EPSILON ? p_no_outliers : 1.0 - DBL_EPSILON;
+                max_trials = (size_t)(log_probability / log(p_no_outliers));      /* :66, a double stored in a size_t */
+            }
+        }
+        ++trial_count;
+    }
+    *trials_run = (int)trial_count;
+    *n_inliers = nbest;
+    int ok = 0;
+    if (nbest > 0) {                                       /* :75-77: the model of ALL inliers of the best trial */
+        for (int k = 0; k < nbest; ++k) {
+            const int i = inliers[k];
+            g[k] = x1[i]; g[n + k] = y1[i]; g[2 * n + k] = x2[i]; g[3 * n + k] = y2[i];
+        }
+        orc_homography_dlt(nbest, g, g + n, g + 2 * n, g + 3 * n, H);
+        ok = 1;
+    }
+    free(g); free(cur); free(res);
+    return ok;
+}
+
 /* ======================================================================== */
 /* tool-level bundle adjustment: hand_eye_registration.cpp:48-238             */
 /* ======================================================================== */

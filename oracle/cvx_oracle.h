@@ -231,6 +231,23 @@ int orc_null_vector9(int m, double *A /* m x 9, destroyed */, double v[9]);
 void orc_homography_residuals(int n, const float *x1, const float *y1, const float *x2, const float *y2,
                               const double H[9], double *res /* n */);
 
+/* ---- HomographyEstimator::solveRansac, homography.cpp:112-156 on cvx::util::RANSAC::estimate, ransac.hpp:28-78 ---- */
+/* PARITY UNPINNED (the reference holds no vectors; its generator is seeded from std::random_device, rng.cpp:6-9, so no
+ * two runs of the reference agree either): the loop is restated on a GIVEN sequence of subsets -- what RNG::sample would
+ * hand it trial after trial -- so that the same sequence gives the same model. */
+typedef struct orc_ransac_params {   /* cvx::util::RANSAC::Parameters, ransac.hpp:12-23 */
+    double max_error, outlier_probability;
+    int max_num_trials, min_inliers;
+} orc_ransac_params;
+void orc_ransac_defaults(orc_ransac_params *p);     /* {0.1, 0.1, 100, 5}: solveRansac builds `RANSAC solver;` (homography.cpp:152) */
+/* RNG::sample(4, N, subset) (rng.hpp:62-75) given the integers its four uniform_int_distribution(0, max_idx) draws return */
+void orc_rng_sample4(int N, const int draw[4], int subset[4]);
+/* subsets: [max_num_trials][4].  Returns estimate()'s value; H (row-major) = the refit on the best trial's inliers,
+ * untouched on failure; inliers[n] (capacity n), *n_inliers; *trials_run = trial_count when the loop ended. */
+int orc_homography_ransac(int n, const float *x1, const float *y1, const float *x2, const float *y2,
+                          const orc_ransac_params *p, const int *subsets, double H[9], int *inliers, int *n_inliers,
+                          int *trials_run);
+
 /* LU solve of the no-LAPACK levmar build (Axb_core.c:992-1139); A, b preserved */
 int orc_lu_solve(int n, const double *A, const double *b, double *x);
 /* dense SPD solve used by the drivers (Cholesky); returns 0 on failure */

@@ -59,6 +59,10 @@ class HandEyeProblem(C.Structure):
 LM_FUNC = C.CFUNCTYPE(None, c_double_p, c_double_p, C.c_int, C.c_int, C.c_void_p)
 
 
+class RansacParams(C.Structure):
+    _fields_ = [("max_error", C.c_double), ("outlier_probability", C.c_double), ("max_num_trials", C.c_int), ("min_inliers", C.c_int)]
+
+
 class ToolBAProblem(C.Structure):
     _fields_ = [("V", C.c_int), ("P", C.c_int), ("N", C.c_int), ("view_off", c_int_p), ("point_id", c_int_p),
                 ("obs_x", c_double_p), ("obs_y", c_double_p), ("trans", c_double_p), ("intr", C.c_double * 9),
@@ -140,6 +144,11 @@ def lib():
         L.orc_null_vector9.argtypes = [C.c_int, dp, dp]
         L.orc_null_vector9.restype = C.c_int
         L.orc_homography_residuals.argtypes = [C.c_int, fp, fp, fp, fp, dp, dp]
+        L.orc_ransac_defaults.argtypes = [C.POINTER(RansacParams)]
+        L.orc_rng_sample4.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_homography_ransac.argtypes = [C.c_int, fp, fp, fp, fp, C.POINTER(RansacParams), C.POINTER(C.c_int), dp,
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_homography_ransac.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -380,3 +389,37 @@ def homography_residuals(x1, y1, x2, y2, H):
     res = np.zeros(len(x1))
     lib().orc_homography_residuals(len(x1), _fp(x1), _fp(y1), _fp(x2), _fp(y2), _dp(H), _dp(res))
     return res
+
+
+def ransac_params(**kw):
+    """cvx::util::RANSAC::Parameters (ransac.hpp:12-23) with the defaults solveRansac runs on"""
+    p = RansacParams()
+    lib().orc_ransac_defaults(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def rng_sample4(N, draw):
+    """RNG::sample(4, N, .) (rng.hpp:62-75) from the four integers its distributions return"""
+    d = (C.c_int * 4)(*[int(x) for x in draw])
+    out = (C.c_int * 4)()
+    lib().orc_rng_sample4(int(N), d, out)
+    return list(out)
+
+
+def homography_ransac(x1, y1, x2, y2, subsets, params=None):
+    """HomographyEstimator::solveRansac (homography.cpp:151-156) on a given sequence of subsets [trials][4]:
+    (ok, H[9] row-major or None, inlier indices, trials run)"""
+    x1, y1, x2, y2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (x1, y1, x2, y2))
+    p = params or ransac_params()
+    sub = np.ascontiguousarray(subsets, dtype=np.int32).reshape(-1, 4)
+    assert sub.shape[0] >= p.max_num_trials
+    n = len(x1)
+    H = np.zeros(9)
+    inl = np.zeros(max(n, 1), dtype=np.int32)
+    ni, tr = C.c_int(0), C.c_int(0)
+    ok = lib().orc_homography_ransac(n, _fp(x1), _fp(y1), _fp(x2), _fp(y2), C.byref(p), sub.ctypes.data_as(C.POINTER(C.c_int)),
+                                     _dp(H), inl.ctypes.data_as(C.POINTER(C.c_int)), C.byref(ni), C.byref(tr))
+    return bool(ok), (H if ok else None), inl[:ni.value].copy(), tr.value
+

@@ -9,7 +9,7 @@ import cvx_amd
 from cvx_amd import capi
 from cvx_amd.problem import HomographyBatch
 from conftest import load_golden
-from test_helpers import homography_batch, homography_problem
+from test_helpers import homography_batch, homography_problem, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -218,3 +218,138 @@ def test_dlt_full_size_batch_properties_and_sampled_parity(orc):
     assert np.all(res.mean(axis=1) < 5.0)
     for i, (ret, Ho) in _dlt_oracle(orc, off, x1, y1, x2, y2, which=range(0, n, 397)).items():
         assert np.max(np.abs(H[i] - Ho)) <= DLT_TOL * np.max(np.abs(Ho)), i
+
+
+# ---- HomographyEstimator::solveRansac for a batch (cvx_homography_ransac) ----
+from test_homography_oracle import draw_subsets, ransac_problem      # noqa: E402
+
+
+def _ransac_batch(orc, rng, sizes, trials, outlier_share=4):
+    parts, subs = [], []
+    for n in sizes:
+        n = int(n)
+        if n >= 4:
+            parts.append(ransac_problem(rng, n, n // outlier_share if outlier_share else 0))
+            subs.append(draw_subsets(orc, rng, n, trials))
+        else:
+            x1, y1, x2, y2, _ = homography_problem(rng, max(n, 1))
+            parts.append((x1[:n], y1[:n], x2[:n], y2[:n]))
+            subs.append(np.zeros((trials, 4), np.int32))
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.int32)
+    cat = lambda k: np.concatenate([p[k] for p in parts])
+    return off, cat(0), cat(1), cat(2), cat(3), np.stack(subs)
+
+
+def _check_against_oracle(orc, off, x1, y1, x2, y2, subsets, params, out, which=None, H_tol=1e-10):
+    for i in (range(len(off) - 1) if which is None else which):
+        s = slice(off[i], off[i + 1])
+        ok, H, inl, trials = orc.homography_ransac(x1[s], y1[s], x2[s], y2[s], subsets[i], orc.ransac_params(**params))
+        assert out["trials_run"][i] == trials, i
+        assert out["n_inliers"][i] == len(inl), i
+        assert np.flatnonzero(out["mask"][s]).tolist() == inl.tolist(), i
+        if ok:
+            # the model of the inliers: the DLT's own bar (DLT_TOL; the null vector comes from different rotations)
+            assert rel_err(out["H"][i], H) < H_tol, (i, rel_err(out["H"][i], H))
+
+
+@pytest.mark.parametrize("params", [dict(max_error=2.0), dict(max_error=0.8, outlier_probability=0.6, max_num_trials=40, min_inliers=8),
+                                    dict(max_error=1e-7, max_num_trials=12)])
+def test_ransac_batch_with_given_subsets_follows_the_oracle(orc, params):
+    rng = np.random.default_rng(41)
+    T = params.get("max_num_trials", 100)
+    sizes = np.concatenate([rng.integers(10, 200, 40), [4, 5, 7, 64, 65, 108, 640, 3, 0, 1024]])
+    off, x1, y1, x2, y2, subsets = _ransac_batch(orc, rng, sizes, T)
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    H_before = np.tile(np.arange(9.0), (b.n, 1))
+    b.set(H_before)
+    out = b.ransac(subsets=subsets, params=params)
+    _check_against_oracle(orc, off, x1, y1, x2, y2, subsets, params, out)
+    none = out["n_inliers"] == 0
+    assert none[-3] and none[-2]                          # fewer than four pairs: estimate() cannot run
+    assert np.array_equal(out["H"][none], H_before[none])   # no model: the estimate stays what it was
+    if params["max_error"] < 1e-6:
+        assert none.all() and (out["trials_run"][sizes >= 4] == T).all()
+    else:
+        assert (out["n_inliers"][sizes >= 12] > 5).all()
+
+
+def test_ransac_subsets_drawn_on_the_device(orc):
+    rng = np.random.default_rng(42)
+    sizes = np.concatenate([rng.integers(8, 150, 30), [4, 5, 108]])
+    off, x1, y1, x2, y2, _ = _ransac_batch(orc, rng, sizes, 1)
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    params = dict(max_error=2.0, max_num_trials=50)
+    out = b.ransac(seed=2026, params=params, want_subsets=True)
+    sub = out["subsets"]
+    for i, n in enumerate(sizes):
+        assert ((sub[i] >= 0) & (sub[i] < n)).all()
+        assert all(len(set(row.tolist())) == 4 for row in sub[i])
+    # RNG::sample's property: uniform over the pairs (a loose check: every pair of the largest problem is drawn sometime)
+    again = b.ransac(seed=2026, params=params, want_subsets=True)
+    other = b.ransac(seed=2027, params=params, want_subsets=True)
+    assert np.array_equal(again["subsets"], sub) and not np.array_equal(other["subsets"], sub)
+    assert np.array_equal(again["H"], out["H"])
+    _check_against_oracle(orc, off, x1, y1, x2, y2, sub, params, out)
+
+
+def test_ransac_rejects_bad_subsets(orc):
+    rng = np.random.default_rng(43)
+    off, x1, y1, x2, y2, subsets = _ransac_batch(orc, rng, [20, 30], 10)
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    for bad in ((1, 3, 2, 30), (0, 0, 0, -1), (1, 2, 0, 2)):        # (problem, trial, slot, value): out of range, negative, repeated
+        s = subsets.copy()
+        s[bad[0], bad[1], bad[2]] = s[bad[0], bad[1], 1] if bad == (1, 2, 0, 2) else bad[3]
+        with pytest.raises(capi.CvxError):
+            b.ransac(subsets=s, params=dict(max_num_trials=10))
+    with pytest.raises(capi.CvxError):
+        b.ransac(seed=1, params=dict(max_num_trials=0))
+    out = b.ransac(subsets=subsets, params=dict(max_num_trials=10, max_error=2.0))     # and the handle still works
+    assert (out["n_inliers"] > 5).all()
+
+
+def test_ransac_then_lm_over_the_inliers_is_the_reference_flow(orc):
+    """solveRansac -> inliers -> solveLM(pts1, pts2, inliers, H) (test_homography.cpp:101-110): the inlier batch that
+    cvx_homography_ransac leaves runs the LM bit for bit as the oracle runs it on the gathered inliers from the same start"""
+    rng = np.random.default_rng(44)
+    sizes = rng.integers(20, 150, 12)
+    params = dict(max_error=2.0)
+    off, x1, y1, x2, y2, subsets = _ransac_batch(orc, rng, sizes, 100)
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    out = b.ransac(subsets=subsets, params=params, keep_inliers=True)
+    nb = out["inliers"]
+    assert nb.off.tolist() == np.concatenate([[0], np.cumsum(out["n_inliers"])]).tolist()
+    res_in = nb.residuals()                             # of the refit, over the inliers only
+    nb.run(100)
+    H, info, ret = nb.get()
+    for i in range(b.n):
+        s = slice(off[i], off[i + 1])
+        inl = np.flatnonzero(out["mask"][s])
+        r, h, inf = orc.homography_lm(x1[s][inl], y1[s][inl], x2[s][inl], y2[s][inl], out["H"][i], itmax=100)
+        assert ret[i] == r and H[i, :8].tolist() == h.tolist() and info[i].tolist() == inf.tolist(), i
+        ref = orc.homography_residuals(x1[s][inl], y1[s][inl], x2[s][inl], y2[s][inl], out["H"][i])
+        assert np.allclose(res_in[nb.off[i]:nb.off[i + 1]], ref, rtol=1e-12, atol=0)
+    nb.close(); b.close()
+
+
+def test_ransac_full_size_batch_properties_and_sampled_parity(orc):
+    """10 000 views x 108 pairs x 100 trials = 1 M hypotheses in one call"""
+    rng = np.random.default_rng(45)
+    n, N, T = 10000, 108, 100
+    parts = [ransac_problem(rng, N, 20) for _ in range(64)]
+    pick = rng.integers(0, 64, n)
+    off = (np.arange(n + 1) * N).astype(np.int32)
+    cat = lambda k: np.concatenate([parts[j][k] for j in pick])
+    x1, y1, x2, y2 = cat(0), cat(1), cat(2), cat(3)
+    b = HomographyBatch(off, x1, y1, x2, y2)
+    params = dict(max_error=2.0)
+    out = b.ransac(seed=7, params=params, want_subsets=True)
+    assert (out["n_inliers"] > 5).all() and (out["n_inliers"] <= 88).all()
+    assert np.array_equal(out["mask"].reshape(n, N).sum(1), out["n_inliers"])
+    assert (out["trials_run"] >= 1).all() and (out["trials_run"] <= T).all()
+    res = b.residuals(out["H"]).reshape(n, N)
+    # (the first acceptable model cuts max_trials to a handful, ransac.hpp:62-66: many problems stop on a mediocre model)
+    good = out["n_inliers"] >= 80                       # the planted outliers are out, and the refit is at the noise level
+    assert good.mean() > 0.2
+    assert np.median(res[good][out["mask"].reshape(n, N)[good] == 1]) < 1.0
+    _check_against_oracle(orc, off, x1, y1, x2, y2, out["subsets"], params, out, which=rng.integers(0, n, 24))
+

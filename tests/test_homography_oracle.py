@@ -157,3 +157,99 @@ def test_dlt_with_fewer_than_four_pairs_is_refused(orc):
     x = np.array([1, 2, 3], np.float32)
     ret, H = orc.homography_dlt(x, x * 2, x + 1, x - 1)
     assert ret == -1 and not H.any()
+
+
+# ---- HomographyEstimator::solveRansac (homography.cpp:112-156 on ransac.hpp:28-78): parity unpinned, see cvx_oracle.h ----
+def _py_sample(N, draw):
+    """rng.hpp:62-75 word for word on a Python list"""
+    vidx, max_idx, subset = list(range(N)), N - 1, []
+    for k in range(4):
+        index = draw[k]
+        vidx[index], vidx[max_idx] = vidx[max_idx], vidx[index]
+        subset.append(vidx[max_idx])
+        max_idx -= 1
+    return subset
+
+
+def ransac_problem(rng, N, outliers, noise=0.3):
+    x1, y1, x2, y2, _ = homography_problem(rng, N, noise=noise)
+    bad = rng.permutation(N)[:outliers]
+    x2 = x2.copy(); y2 = y2.copy()
+    x2[bad] += rng.uniform(20, 200, outliers).astype(np.float32) * rng.choice([-1, 1], outliers).astype(np.float32)
+    y2[bad] += rng.uniform(20, 200, outliers).astype(np.float32)
+    return x1, y1, x2, y2
+
+
+def draw_subsets(orc, rng, N, trials):
+    return np.array([orc.rng_sample4(N, [int(rng.integers(0, N - k)) for k in range(4)]) for _ in range(trials)], dtype=np.int32)
+
+
+def _py_ransac(orc, x1, y1, x2, y2, subsets, p):
+    """ransac.hpp:28-78 in Python on the oracle's solve() and residuals(), which other tests pin"""
+    n = len(x1)
+    log_probability, one_over = np.log(1.0 - p.outlier_probability), 1.0 / n
+    trial, max_trials, min_residual, best = 0, p.max_num_trials, np.finfo(np.float64).max, None
+    while trial < min(p.max_num_trials, max_trials):
+        s = subsets[trial]
+        _, H = orc.homography_dlt(x1[s], y1[s], x2[s], y2[s])
+        with np.errstate(all="ignore"):
+            res = orc.homography_residuals(x1, y1, x2, y2, H)
+            inl = np.flatnonzero(res < p.max_error)
+            total = 0.0
+            for i in inl:
+                total += res[i]
+            total = total / len(inl) if len(inl) else float("nan")
+        if len(inl) > p.min_inliers and total < min_residual:
+            min_residual, best = total, inl
+            pno = 1.0 - (len(inl) * one_over) ** 4
+            pno = min(max(pno, np.finfo(np.float64).eps), 1.0 - np.finfo(np.float64).eps)
+            max_trials = int(log_probability / np.log(pno))
+        trial += 1
+    if best is None:
+        return False, None, np.zeros(0, int), trial
+    _, H = orc.homography_dlt(x1[best], y1[best], x2[best], y2[best])
+    return True, H, best, trial
+
+
+def test_sample_is_the_reference_swap_sequence(orc):
+    rng = np.random.default_rng(5)
+    for N in (4, 5, 9, 108, 1000):
+        for _ in range(50):
+            draw = [int(rng.integers(0, N - k)) for k in range(4)]
+            s = orc.rng_sample4(N, draw)
+            assert s == _py_sample(N, draw) and len(set(s)) == 4 and all(0 <= v < N for v in s)
+
+
+@pytest.mark.parametrize("case", ["outliers", "tight_threshold", "all_inliers", "few_trials", "nothing_qualifies"])
+def test_ransac_loop_follows_the_reference_loop(orc, case):
+    rng = np.random.default_rng({"outliers": 1, "tight_threshold": 2, "all_inliers": 3, "few_trials": 4, "nothing_qualifies": 5}[case])
+    kw = dict(outliers=dict(max_error=2.0), tight_threshold=dict(max_error=0.6, outlier_probability=0.5, max_num_trials=60),
+              all_inliers=dict(max_error=50.0), few_trials=dict(max_error=1.5, max_num_trials=3, min_inliers=20),
+              nothing_qualifies=dict(max_error=1e-6))[case]
+    p = orc.ransac_params(**kw)
+    stopped_early = 0
+    for rep in range(6):
+        N = int(rng.integers(12, 109))
+        x1, y1, x2, y2 = ransac_problem(rng, N, outliers=0 if case == "all_inliers" else N // 4)
+        subsets = draw_subsets(orc, rng, N, p.max_num_trials)
+        ok, H, inl, trials = orc.homography_ransac(x1, y1, x2, y2, subsets, p)
+        ok2, H2, inl2, trials2 = _py_ransac(orc, x1, y1, x2, y2, subsets, p)
+        assert (ok, trials) == (ok2, trials2) and inl.tolist() == list(inl2)
+        if ok:
+            assert H.tolist() == H2.tolist()
+            stopped_early += trials < p.max_num_trials
+            assert len(inl) > p.min_inliers
+        else:
+            assert trials == p.max_num_trials and len(inl) == 0
+    if case == "nothing_qualifies":
+        assert not ok
+    if case in ("outliers", "all_inliers"):
+        assert stopped_early > 0          # the first acceptable model cuts max_trials (ransac.hpp:62-66)
+
+
+def test_ransac_needs_four_pairs(orc):
+    rng = np.random.default_rng(6)
+    x1, y1, x2, y2 = ransac_problem(rng, 12, 0)
+    ok, H, inl, trials = orc.homography_ransac(x1[:3], y1[:3], x2[:3], y2[:3], np.zeros((100, 4), np.int32))
+    assert not ok and trials == 0 and len(inl) == 0
+
