@@ -170,6 +170,48 @@ def homography_bench(cvx_amd, torch, device, with_cpu, n=CAMERAS * VIEWS_PER_CAM
            "dlt": {"ms_per_batch": 1e3 * dt_dlt, "problems_per_s": n / dt_dlt, "ms_per_batch_dlt_then_lm": 1e3 * dt_both,
                    "mean_transfer_residual_px": float(res.mean()),
                    "kernels": "k_homography_dlt_reduce + k_homography_dlt_finish, estimates left on the device"}}
+    # and the step before that, HomographyEstimator::solveRansac (homography.cpp:151-156): the same views with 20 of the 108
+    # pairs pushed 20-200 px away, RANSAC::Parameters' defaults but max_error = 2 px (the default 0.1 px is below the noise),
+    # subsets drawn on the device; then solveLM over each view's inliers
+    bad = rng.permutation(P)[:20]
+    x2o = x2.reshape(n, P).copy(); y2o = y2.reshape(n, P).copy()
+    x2o[:, bad] += rng.uniform(20, 200, (n, 20)).astype(np.float32); y2o[:, bad] -= rng.uniform(20, 200, (n, 20)).astype(np.float32)
+    x2o = x2o.ravel(); y2o = y2o.ravel()
+    br = HomographyBatch(off, x1, y1, x2o, y2o, device=device)
+    rparams = dict(max_error=2.0)
+    br.ransac(seed=SEED, params=rparams)
+    t = time.perf_counter()
+    for _ in range(3):
+        rout = br.ransac(seed=SEED, params=rparams)
+    dt_r = (time.perf_counter() - t) / 3
+    t = time.perf_counter()
+    rk = br.ransac(seed=SEED, params=rparams, keep_inliers=True)
+    rk["inliers"].run()
+    Hl, _, retl = rk["inliers"].get()
+    dt_rl = time.perf_counter() - t
+    rk["inliers"].close()
+    out["ransac"] = {"ms_per_batch": 1e3 * dt_r, "problems_per_s": n / dt_r, "hypotheses_per_batch": n * 100,
+                     "hypotheses_per_s": n * 100 / dt_r, "ms_ransac_then_lm_over_inliers": 1e3 * dt_rl,
+                     "mean_inliers": float(rout["n_inliers"].mean()), "mean_trials_the_loop_ran": float(rout["trials_run"].mean()),
+                     "planted_outliers_among_inliers": int(rout["mask"].reshape(n, P)[:, bad].sum()),
+                     "lm_converged": int(np.sum(retl > 0)),
+                     "note": "all 100 trials of every view fitted (DLT on four pairs) and scored at once, the reference's loop "
+                             "walked over the scores; H, inlier counts, the inlier mask and trial counts downloaded"}
+    if with_cpu:
+        from oracle import oracle as orc
+        m = 100
+        ru = br.ransac(seed=SEED, params=rparams, want_subsets=True)
+        t = time.perf_counter()
+        same = 0
+        for i in range(m):
+            sl = slice(off[i], off[i + 1])
+            ok, Ho, inl, tr = orc.homography_ransac(x1[sl], y1[sl], x2o[sl], y2o[sl], ru["subsets"][i], orc.ransac_params(**rparams))
+            same += int(np.flatnonzero(ru["mask"][sl]).tolist() == inl.tolist() and tr == ru["trials_run"][i])
+        dtc = time.perf_counter() - t
+        out["ransac"]["cpu_baseline"] = {"value": m / dtc, "unit": "problems/s", "cores": 1, "kind": "port",
+                                         "sample": "first %d of the %d problems on the subsets the device drew (the loop stops after %.1f trials on average), %.2f s" % (m, n, float(ru["trials_run"][:m].mean()), dtc),
+                                         "same_inliers_and_trial_count_as_gpu": "%d of %d" % (same, m)}
+    br.close()
     if with_cpu:
         from oracle import oracle as orc
         kind = "reference" if orc.levmar_ref() is not None else "port"

@@ -250,11 +250,10 @@ extern "C" int cvx_homography_ransac(cvx_homography *h, const cvx_ransac_params 
     CVX_HIP(hipMalloc(&nb->d_W, sizeof(double) * DLT_W * n));
     // everything of the hypothesis batch in one block
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_off = up(sizeof(int) * (Mz + 1)), b_pts = up(sizeof(float) * 16 * Mz), b_W = up(sizeof(double) * DLT_W * Mz),
-                 b_H = up(sizeof(double) * 9 * Mz), b_cnt = up(sizeof(int) * Mz), b_mean = up(sizeof(double) * Mz),
+    const size_t b_pts = up(sizeof(float) * 16 * Mz), b_H = up(sizeof(double) * 9 * Mz), b_cnt = up(sizeof(int) * Mz), b_mean = up(sizeof(double) * Mz),
                  b_sub = up(sizeof(int) * 4 * Mz), b_per = up(sizeof(int) * n), b_mask = up(tot), b_flags = 256;
     char *block = nullptr;
-    CVX_HIP(hipMalloc((void **)&block, b_off + b_pts + b_W + b_H + b_cnt + b_mean + 2 * b_sub + 3 * b_per + b_mask + b_flags));
+    CVX_HIP(hipMalloc((void **)&block, b_pts + b_H + b_cnt + b_mean + 2 * b_sub + 3 * b_per + b_mask + b_flags));
     struct Free { char *p; ~Free() { if (p) (void)hipFree(p); } } guard{block};
     char *q = block;
     RansacArgs a;
@@ -263,9 +262,7 @@ extern "C" int cvx_homography_ransac(cvx_homography *h, const cvx_ransac_params 
     a.n_problems = h->n; a.T = p.max_num_trials;
     a.seed = seed;
     a.max_error = p.max_error; a.log_probability = std::log(1.0 - p.outlier_probability); a.min_inliers = p.min_inliers;
-    a.hyp_off = reinterpret_cast<int *>(q); q += b_off;
     a.hx1 = reinterpret_cast<float *>(q); a.hy1 = a.hx1 + 4 * Mz; a.hx2 = a.hx1 + 8 * Mz; a.hy2 = a.hx1 + 12 * Mz; q += b_pts;
-    double *hyp_W = reinterpret_cast<double *>(q); q += b_W;
     double *hyp_H = reinterpret_cast<double *>(q); q += b_H;
     a.hyp_H = hyp_H;
     a.cnt = reinterpret_cast<int *>(q); q += b_cnt;
@@ -287,13 +284,8 @@ extern "C" int cvx_homography_ransac(cvx_homography *h, const cvx_ransac_params 
     a.nx1 = nb->d_pts; a.ny1 = nb->d_pts + nb->tp; a.nx2 = nb->d_pts + 2 * nb->tp; a.ny2 = nb->d_pts + 3 * nb->tp;
     CVX_HIP(hipMemsetAsync(a.flags, 0, sizeof(int), s));
     CVX_HIP(hipMemsetAsync(a.mask, 0, tot, s));
-    CVX_HIP(hipMemsetAsync(hyp_H, 0, sizeof(double) * 9 * Mz, s));
-    hipLaunchKernelGGL(k_hom_ransac_gather, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, s, a);
-    CVX_HIP(hipGetLastError());
-    DltArgs d;
-    d.off = a.hyp_off; d.x1 = a.hx1; d.y1 = a.hy1; d.x2 = a.hx2; d.y2 = a.hy2; d.W = hyp_W; d.H = hyp_H; d.n_problems = (int)M;
-    st = launch_dlt(d, 4, s);
-    if (st) return st;
+    hipLaunchKernelGGL(k_hom_ransac_gather, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_hom_ransac_fit4, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, a, hyp_H);
     hipLaunchKernelGGL(k_hom_ransac_score, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_hom_ransac_select, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_hom_ransac_offsets, dim3(1), dim3(1024), 0, s, a);

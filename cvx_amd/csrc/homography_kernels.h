@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64) void k_homography_residuals(DltArgs a, double *
 //   k_hom_ransac_gather    the four pairs of every hypothesis, from the caller's subsets (what RNG::sample draws, rng.hpp:62-75)
 //                          or drawn here from a seed (a counter-based generator: the reference seeds std::mt19937_64 from
 //                          std::random_device, rng.cpp:6-9, so there is no sequence of its own to reproduce)
-//   k_homography_dlt_*     the models (the batch of four-pair problems is an ordinary DLT batch)
+//   k_hom_ransac_fit4      the models: solve() on four pairs, one lane per hypothesis
 //   k_hom_ransac_score     findInliers (homography.cpp:131-144): one lane per hypothesis, the residuals added in index order
 //   k_hom_ransac_select    the loop of ransac.hpp:44-73 on the scores
 //   k_hom_ransac_offsets   where each problem's inliers go in the refit batch (exclusive scan)
@@ -647,8 +647,7 @@ struct RansacArgs {
     unsigned long long seed;
     double max_error, log_probability;
     int min_inliers;
-    int *hyp_off;                            // [M + 1], M = n_problems * T
-    float *hx1, *hy1, *hx2, *hy2;            // [4 M]
+    float *hx1, *hy1, *hx2, *hy2;            // [4 M], M = n_problems * T
     int *subsets_used;                       // [M][4]
     const double *hyp_H;                     // [M][9]
     int *cnt;                                // [M]
@@ -670,9 +669,7 @@ __device__ __forceinline__ unsigned long long hom_mix64(unsigned long long z) { 
 __global__ __launch_bounds__(256) void k_hom_ransac_gather(RansacArgs a) {
     const long long M = (long long)a.n_problems * a.T;
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m > M) return;
-    if (m == M) { a.hyp_off[M] = (int)(4 * M); return; }
-    a.hyp_off[m] = (int)(4 * m);
+    if (m >= M) return;
     const int prob = (int)(m / a.T);
     const int o0 = a.off[prob], N = a.off[prob + 1] - o0;
     int sub[4] = {0, 0, 0, 0};
@@ -712,6 +709,132 @@ __global__ __launch_bounds__(256) void k_hom_ransac_gather(RansacArgs a) {
         a.hx2[4 * m + k] = ok ? a.x2[i] : 0.f; a.hy2[4 * m + k] = ok ? a.y2[i] : 0.f;
         if (a.subsets_used) a.subsets_used[4 * m + k] = ok ? sub[k] : -1;
     }
+}
+
+// The model of a trial: HomographyEstimator::solve on FOUR pairs, one lane per hypothesis, everything in registers.
+// normalize_points and the constraint matrix as k_homography_dlt_reduce makes them (the same float arithmetic in the same
+// order); the null vector of the 8 x 9 matrix -- for a full-rank matrix the same direction whatever finds it -- by
+// Householder QR with column pivoting and a back substitution with the column left over set to one (rank revealing: the
+// free column is the most dependent one, so the triangle it leaves is as well conditioned as the subset allows); swaps are
+// selects, so that no index is dynamic.  (The general kernels on a batch of a million four-pair problems: 21 ms of
+// a 25 ms call -- a wave and 83 KB of LDS per 64 problems are sized for hundreds of pairs; this: 0.3 ms.)
+template <int k>
+__device__ __forceinline__ void hom_qrcp_step(double (&A)[8][9], int (&perm)[9]) {
+    double best = -1.0;
+    int p = k;
+#pragma unroll
+    for (int j = k; j < 9; ++j) {
+        double ss = 0.0;
+#pragma unroll
+        for (int i = k; i < 8; ++i) ss += A[i][j] * A[i][j];
+        if (ss > best) { best = ss; p = j; }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 9; ++j) {
+        const bool sw = (j == p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double t = A[i][k], u = A[i][j];
+            A[i][k] = sw ? u : t; A[i][j] = sw ? t : u;
+        }
+        const int tp = perm[k], up = perm[j];
+        perm[k] = sw ? up : tp; perm[j] = sw ? tp : up;
+    }
+    const double akk = A[k][k];
+    if (best > 0.0) {
+        const double alpha = akk > 0.0 ? -sqrt(best) : sqrt(best);
+        const double beta = 1.0 / (best - akk * alpha);
+        const double vk = akk - alpha;
+#pragma unroll
+        for (int j = k + 1; j < 9; ++j) {
+            double d = vk * A[k][j];
+#pragma unroll
+            for (int i = k + 1; i < 8; ++i) d += A[i][k] * A[i][j];
+            d *= beta;
+            A[k][j] -= d * vk;
+#pragma unroll
+            for (int i = k + 1; i < 8; ++i) A[i][j] -= d * A[i][k];
+        }
+        A[k][k] = alpha;
+    }
+}
+
+__device__ __forceinline__ void hom_null_vector_8x9(double (&A)[8][9], double v[9]) {
+    int perm[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) perm[c] = c;
+    // (eight instantiations, not a loop: every index of A must be a constant for A to live in registers)
+    hom_qrcp_step<0>(A, perm); hom_qrcp_step<1>(A, perm); hom_qrcp_step<2>(A, perm); hom_qrcp_step<3>(A, perm);
+    hom_qrcp_step<4>(A, perm); hom_qrcp_step<5>(A, perm); hom_qrcp_step<6>(A, perm); hom_qrcp_step<7>(A, perm);
+    double w[9];
+    w[8] = 1.0;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < 9; ++j) sum += A[i][j] * w[j];
+        w[i] = -sum / A[i][i];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) v[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) v[c] = (perm[j] == c) ? w[j] : v[c];
+}
+
+__global__ __launch_bounds__(64) void k_hom_ransac_fit4(RansacArgs a, double *hyp_H) {
+    const long long M = (long long)a.n_problems * a.T;
+    const long long m = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    const float4 X1 = reinterpret_cast<const float4 *>(a.hx1)[m], Y1 = reinterpret_cast<const float4 *>(a.hy1)[m];
+    const float4 X2 = reinterpret_cast<const float4 *>(a.hx2)[m], Y2 = reinterpret_cast<const float4 *>(a.hy2)[m];
+    const float px[4][4] = {{X1.x, X1.y, X1.z, X1.w}, {Y1.x, Y1.y, Y1.z, Y1.w}, {X2.x, X2.y, X2.z, X2.w}, {Y2.x, Y2.y, Y2.z, Y2.w}};
+    float ctr[4];
+    double scale[2];
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {           // homography.cpp:20-24: the sums in point order, in float
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sum = sum + px[q][i];
+            ctr[q] = sum / 4.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {           // :26-32
+            float nrm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dx = px[2 * q][i] - ctr[2 * q], dy = px[2 * q + 1][i] - ctr[2 * q + 1];
+                const float xx = dx * dx, yy = dy * dy;
+                const float d = xx + yy;
+                nrm = nrm + d;
+            }
+            nrm = nrm / 4.0f;
+            scale[q] = sqrt(2.0) / (double)sqrtf(nrm);
+        }
+    }
+    double A[8][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double u1 = (double)(float)((double)(px[0][i] - ctr[0]) * scale[0]), v1 = (double)(float)((double)(px[1][i] - ctr[1]) * scale[0]);
+        const double u2 = (double)(float)((double)(px[2][i] - ctr[2]) * scale[1]), v2 = (double)(float)((double)(px[3][i] - ctr[3]) * scale[1]);
+        double *r0 = A[2 * i], *r1 = A[2 * i + 1];
+        r0[0] = u1; r0[1] = v1; r0[2] = 1.0; r0[3] = 0.0; r0[4] = 0.0; r0[5] = 0.0; r0[6] = -u2 * u1; r0[7] = -u2 * v1; r0[8] = -u2;
+        r1[0] = 0.0; r1[1] = 0.0; r1[2] = 0.0; r1[3] = -u1; r1[4] = -v1; r1[5] = -1.0; r1[6] = v2 * u1; r1[7] = v2 * v1; r1[8] = v2;
+    }
+    double v[9], T1[9], T2[9], T2i[9], Mx[9], Hh[9];
+    hom_null_vector_8x9(A, v);
+    const double s1 = scale[0], s2 = scale[1], cx1 = ctr[0], cy1 = ctr[1], cx2 = ctr[2], cy2 = ctr[3];
+    T1[0] = s1; T1[1] = 0.0; T1[2] = -s1 * cx1; T1[3] = 0.0; T1[4] = s1; T1[5] = -s1 * cy1; T1[6] = 0.0; T1[7] = 0.0; T1[8] = 1.0;
+    T2[0] = s2; T2[1] = 0.0; T2[2] = -s2 * cx2; T2[3] = 0.0; T2[4] = s2; T2[5] = -s2 * cy2; T2[6] = 0.0; T2[7] = 0.0; T2[8] = 1.0;
+    hom_inverse3(T2, T2i);
+    hom_mul3(T2i, v, Mx);
+    hom_mul3(Mx, T1, Hh);
+    const double h22 = Hh[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) hyp_H[9 * m + i] = Hh[i] / h22;
 }
 
 // the residual of homography.cpp:105-108 for one pair

@@ -419,7 +419,7 @@ int cvx_homography_residuals(cvx_homography *h, const double *H, double *res);
  * trials_run[n_problems] (trial_count when the loop ended), subsets_used[n_problems][max_num_trials][4] (-1 for problems
  * with fewer than 4 pairs), inlier_batch = a new handle (the caller destroys it) whose problems are the inliers in index
  * order with the refit as current estimates: cvx_homography_run on it is solveLM(pts1, pts2, inliers, H) (:218-236).
- * n_problems x max_num_trials beyond CVX_RANSAC_MAX_HYPOTHESES: CVX_ERR_UNSUPPORTED (704 bytes of work space each). */
+ * n_problems x max_num_trials beyond CVX_RANSAC_MAX_HYPOTHESES: CVX_ERR_UNSUPPORTED (180 bytes of work space each). */
 #define CVX_RANSAC_MAX_HYPOTHESES (1 << 23)
 typedef struct cvx_ransac_params {
     double max_error;             /* 0.1 */

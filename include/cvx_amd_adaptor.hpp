@@ -20,6 +20,7 @@
 #include <cmath>
 #include <stdexcept>
 #include <string>
+#include <random>
 #include <vector>
 
 #include "cvx_amd.h"
@@ -351,6 +352,98 @@ void homography_residuals_batch(const std::vector<const std::vector<Point> *> &p
     cvx_homography_destroy(hh);
     check(st, "cvx_homography_residuals");
     for (size_t i = 0; i < n; ++i) res[i].assign(r.begin() + off[i], r.begin() + off[i + 1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// bool HomographyEstimator::solveRansac(pts1, pts2, H, inliers)   homography.cpp:151-156 on RANSAC::estimate, ransac.hpp:28-78
+// for a batch of views.  The subsets are drawn HERE, with the reference's own generator type and calls (RNG::sample,
+// rng.hpp:62-75: std::mt19937_64, std::uniform_int_distribution<>(0, max_idx), the swap), trial after trial and view after
+// view, so a generator seeded like the reference's picks what the reference's picks; rng_seed = nullptr seeds it from
+// std::random_device as RNG::RNG() does (rng.cpp:6-9).  Unlike the reference's loop, every view draws all
+// max_num_trials subsets (the device scores them at once; the loop's early exit is taken on the scores), so with one
+// generator for several views a view's draws begin where the previous view's hundred end.  refine_iterations > 0 goes on
+// to solveLM over each view's inliers (test_homography.cpp:101-110) without the estimates leaving the device.
+// ok[i] = what estimate() returns for view i; H[i] is written only then (resized to the batch otherwise untouched).
+// ------------------------------------------------------------------------------------------
+struct ransac_parameters {        // cvx::util::RANSAC::Parameters (ransac.hpp:12-23)
+    double max_error_ = 0.1, outlier_probability_ = 0.1;
+    size_t max_num_trials_ = 100, min_inliers_ = 5;
+};
+
+template <class Point, class Mat3>
+void homography_solve_ransac_batch(const std::vector<const std::vector<Point> *> &pts1,
+                                   const std::vector<const std::vector<Point> *> &pts2, std::vector<Mat3> &H,
+                                   std::vector<std::vector<size_t>> &inliers, std::vector<char> &ok,
+                                   const ransac_parameters &params = ransac_parameters(), const uint64_t *rng_seed = nullptr,
+                                   int refine_iterations = 0, int device = 0, void *stream = nullptr) {
+    const size_t n = pts1.size();
+    H.resize(n); inliers.assign(n, std::vector<size_t>()); ok.assign(n, 0);
+    if (n == 0) return;
+    std::vector<int> off;
+    cvx_homography *hh = detail::homography_handle(pts1, pts2, off, device, stream);
+    const size_t T = params.max_num_trials_;
+    std::vector<int> subsets(n * T * 4, 0);
+    {
+        std::mt19937_64 generator;
+        if (rng_seed) generator.seed(*rng_seed);
+        else { std::random_device rd; generator.seed(rd()); }
+        std::vector<int> vidx;
+        for (size_t i = 0; i < n; ++i) {
+            const int N = off[i + 1] - off[i];
+            if (N < 4) continue;                                   // assert(N <= n), ransac.hpp:32
+            vidx.resize((size_t)N);
+            for (size_t t = 0; t < T; ++t) {
+                for (int k = 0; k < N; ++k) vidx[(size_t)k] = k;
+                int max_idx = N - 1;
+                for (int k = 0; k < 4; ++k) {
+                    std::uniform_int_distribution<> ud(0, max_idx);
+                    const int index = ud(generator);
+                    std::swap(vidx[(size_t)index], vidx[(size_t)max_idx]);
+                    subsets[(i * T + t) * 4 + (size_t)k] = vidx[(size_t)max_idx];
+                    --max_idx;
+                }
+            }
+        }
+    }
+    cvx_ransac_params p;
+    p.max_error = params.max_error_; p.outlier_probability = params.outlier_probability_;
+    p.max_num_trials = (int)params.max_num_trials_; p.min_inliers = (int)params.min_inliers_;
+    std::vector<double> h(9 * n, 0.0);
+    std::vector<int> cnt(n, 0);
+    std::vector<unsigned char> mask((size_t)(off[n] > 0 ? off[n] : 1), 0);
+    cvx_homography *nb = nullptr;
+    int st = cvx_homography_ransac(hh, &p, subsets.data(), 0, h.data(), cnt.data(), mask.data(), nullptr, nullptr,
+                                   refine_iterations > 0 ? &nb : nullptr);
+    if (!st && nb) {
+        st = cvx_homography_run(nb, refine_iterations, nullptr);
+        if (!st) st = cvx_homography_get(nb, h.data(), nullptr, nullptr);
+    }
+    if (nb) cvx_homography_destroy(nb);
+    cvx_homography_destroy(hh);
+    check(st, "cvx_homography_ransac");
+    for (size_t i = 0; i < n; ++i) {
+        if (cnt[i] == 0) continue;                                 // best_subset.empty(): estimate() returns false, H untouched
+        ok[i] = 1;
+        for (int k = off[i]; k < off[i + 1]; ++k)
+            if (mask[(size_t)k]) inliers[i].push_back((size_t)(k - off[i]));
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) H[i](r, c) = h[9 * i + 3 * (size_t)r + (size_t)c];
+    }
+}
+
+// the reference's single-view signature (plus the parameters it leaves at their defaults, and the seed)
+template <class Point, class Mat3>
+bool homography_solve_ransac(const std::vector<Point> &pts1, const std::vector<Point> &pts2, Mat3 &H,
+                             std::vector<size_t> &inliers, const ransac_parameters &params = ransac_parameters(),
+                             const uint64_t *rng_seed = nullptr, int device = 0, void *stream = nullptr) {
+    std::vector<Mat3> Hs(1, H);
+    std::vector<std::vector<size_t>> in;
+    std::vector<char> ok;
+    homography_solve_ransac_batch<Point, Mat3>({&pts1}, {&pts2}, Hs, in, ok, params, rng_seed, 0, device, stream);
+    if (!ok[0]) return false;
+    H = Hs[0];
+    inliers = in[0];                                               // best_subset = inliers (ransac.hpp:58)
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------

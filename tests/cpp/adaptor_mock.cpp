@@ -141,6 +141,32 @@ int main() {
     for (size_t i = 0; i < hres[0].size(); ++i) std::printf("%s%.17g", i ? ", " : "", hres[0][i]);
     std::printf("], ");
 
+    // HomographyEstimator::solveRansac on the same view with every 7th pair pushed away; twice from one seed
+    {
+        std::vector<Pt2f> c2 = b2;
+        for (size_t i = 0; i < c2.size(); i += 7) { c2[i].x += 40.f; c2[i].y -= 25.f; }
+        cvx_amd::ransac_parameters rp;
+        rp.max_error_ = 2.0;
+        const uint64_t seed = 20260007;
+        for (int rep = 0; rep < 2; ++rep) {
+            Mat3 Hr;
+            for (int i = 0; i < 9; ++i) Hr.m[i] = -1.0;
+            std::vector<size_t> rin;
+            bool rok = false;
+            try {
+                rok = cvx_amd::homography_solve_ransac(b1, c2, Hr, rin, rp, &seed);
+            } catch (const std::exception &e) {
+                std::fprintf(stderr, "%s\n", e.what());
+                return 9;
+            }
+            std::printf("\"ransac_ok%d\": %d, \"ransac_H%d\": [", rep, rok ? 1 : 0, rep);
+            for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", Hr.m[i]);
+            std::printf("], \"ransac_inliers%d\": [", rep);
+            for (size_t i = 0; i < rin.size(); ++i) std::printf("%s%zu", i ? ", " : "", rin[i]);
+            std::printf("], ");
+        }
+    }
+
     // bundleAdjustment of tools/hand_eye_registration.cpp on the same detections: the "gripper" transforms are
     // chosen so that pose * trans_v equals each view's ground-truth board pose; start = a perturbed pose, inverted
     // on entry like the tool does (:431-432)

@@ -79,6 +79,16 @@ def test_adaptor_refine_and_handeye_match_oracle(orc):
     assert rd > 0 and np.max(np.abs(np.array(out["hom_dlt"]) - Hd)) <= 1e-13 * np.max(np.abs(Hd))
     ro = orc.homography_residuals(a1, b1, a2, b2, np.array(out["hom_dlt"]))
     assert np.max(np.abs(np.array(out["hom_dlt_res"]) - ro)) <= 1e-11 * max(1.0, np.max(ro))
+    # HomographyEstimator::solveRansac: every 7th pair was pushed away; the model is solve() on the inliers (ransac.hpp:77),
+    # the inliers are the pairs within max_error of SOME four-pair model, and one seed gives one answer
+    assert out["ransac_ok0"] == 1 and out["ransac_ok1"] == 1
+    assert out["ransac_H0"] == out["ransac_H1"] and out["ransac_inliers0"] == out["ransac_inliers1"]
+    inl = np.array(out["ransac_inliers0"])
+    assert len(inl) > 5 and not set(inl.tolist()) & set(range(0, o1 - o0, 7))
+    c2, e2 = a2.copy(), b2.copy()
+    c2[::7] += 40; e2[::7] -= 25
+    rr, Hr = orc.homography_dlt(a1[inl], b1[inl], c2[inl], e2[inl])
+    assert rr > 0 and np.max(np.abs(np.array(out["ransac_H0"]) - Hr)) <= 1e-11 * np.max(np.abs(Hr))
     # tool-level bundle adjustment: same problem rebuilt here and solved by the oracle
     from oracle import oracle as orc_mod
     wg = np.array([0.1, -0.2, 0.15]); tg = np.array([10.0, -20.0, 30.0])
