@@ -23,11 +23,13 @@ struct cvx_homography {
     float *d_pts = nullptr;          // x1 | y1 | x2 | y2, `total` each
     double *d_H = nullptr, *d_info = nullptr;
     double *d_W = nullptr, *d_res = nullptr;     // DLT work records / transfer residuals, made on first use
+    char *d_ransac = nullptr;                    // cvx_homography_ransac's work block, kept for the next call (180 B per hypothesis)
+    size_t ransac_cap = 0;
     size_t lds_bytes = 0;
     ~cvx_homography() {
         (void)hipSetDevice(device);
         // d_pts heads the handle's one device block (offsets, estimates, info, return values behind it)
-        for (void *p : {(void *)d_pts, (void *)d_W, (void *)d_res})
+        for (void *p : {(void *)d_pts, (void *)d_W, (void *)d_res, (void *)d_ransac})
             if (p) (void)hipFree(p);
         if (own_stream) cvx::own_stream_end(device, stream);
     }
@@ -252,10 +254,13 @@ extern "C" int cvx_homography_ransac(cvx_homography *h, const cvx_ransac_params 
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_pts = up(sizeof(float) * 16 * Mz), b_H = up(sizeof(double) * 9 * Mz), b_cnt = up(sizeof(int) * Mz), b_mean = up(sizeof(double) * Mz),
                  b_sub = up(sizeof(int) * 4 * Mz), b_per = up(sizeof(int) * n), b_mask = up(tot), b_flags = 256;
-    char *block = nullptr;
-    CVX_HIP(hipMalloc((void **)&block, b_pts + b_H + b_cnt + b_mean + 2 * b_sub + 3 * b_per + b_mask + b_flags));
-    struct Free { char *p; ~Free() { if (p) (void)hipFree(p); } } guard{block};
-    char *q = block;
+    const size_t need = b_pts + b_H + b_cnt + b_mean + 2 * b_sub + 3 * b_per + b_mask + b_flags;
+    if (h->ransac_cap < need) {
+        if (h->d_ransac) { CVX_HIP(hipStreamSynchronize(s)); (void)hipFree(h->d_ransac); h->d_ransac = nullptr; h->ransac_cap = 0; }
+        CVX_HIP(hipMalloc((void **)&h->d_ransac, need));
+        h->ransac_cap = need;
+    }
+    char *q = h->d_ransac;
     RansacArgs a;
     a.off = h->d_off;
     a.x1 = h->d_pts; a.y1 = h->d_pts + h->tp; a.x2 = h->d_pts + 2 * h->tp; a.y2 = h->d_pts + 3 * h->tp;
