@@ -165,6 +165,21 @@ int main() {
             for (size_t i = 0; i < rin.size(); ++i) std::printf("%s%zu", i ? ", " : "", rin[i]);
             std::printf("], ");
         }
+        // the batch form, going on to solveLM over the inliers (two views: this one and the clean one)
+        std::vector<Mat3> Hb;
+        std::vector<std::vector<size_t>> inb;
+        std::vector<char> okb;
+        try {
+            cvx_amd::homography_solve_ransac_batch<Pt2f, Mat3>({&b1, &b1}, {&c2, &b2}, Hb, inb, okb, rp, &seed, 100);
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return 10;
+        }
+        std::printf("\"ransac_lm_ok\": [%d, %d], \"ransac_lm_H\": [", (int)okb[0], (int)okb[1]);
+        for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", Hb[0].m[i]);
+        std::printf("], \"ransac_lm_inliers\": [");
+        for (size_t i = 0; i < inb[0].size(); ++i) std::printf("%s%zu", i ? ", " : "", inb[0][i]);
+        std::printf("], \"ransac_lm_inliers_clean\": %zu, ", inb[1].size());
     }
 
     // bundleAdjustment of tools/hand_eye_registration.cpp on the same detections: the "gripper" transforms are

@@ -89,6 +89,12 @@ def test_adaptor_refine_and_handeye_match_oracle(orc):
     c2[::7] += 40; e2[::7] -= 25
     rr, Hr = orc.homography_dlt(a1[inl], b1[inl], c2[inl], e2[inl])
     assert rr > 0 and np.max(np.abs(np.array(out["ransac_H0"]) - Hr)) <= 1e-11 * np.max(np.abs(Hr))
+    # the batch form with refine_iterations: view 0 draws the same first hundred subsets as the single call (same seed), so
+    # the same inliers and refit; then solveLM over them, bit for bit the oracle's LM from that refit
+    assert out["ransac_lm_ok"] == [1, 1] and out["ransac_lm_inliers"] == out["ransac_inliers0"]
+    assert out["ransac_lm_inliers_clean"] > len(inl)
+    rl, hl, _ = orc.homography_lm(a1[inl], b1[inl], c2[inl], e2[inl], np.array(out["ransac_H0"]))
+    assert rl > 0 and out["ransac_lm_H"][:8] == hl.tolist() and out["ransac_lm_H"][8] == 1.0
     # tool-level bundle adjustment: same problem rebuilt here and solved by the oracle
     from oracle import oracle as orc_mod
     wg = np.array([0.1, -0.2, 0.15]); tg = np.array([10.0, -20.0, 30.0])
