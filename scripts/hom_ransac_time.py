@@ -5,6 +5,8 @@ import numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+if os.environ.get('WITH_TORCH'):
+    import torch; torch.cuda.init()
 import cvx_amd
 from cvx_amd.problem import HomographyBatch
 from test_homography_oracle import ransac_problem
@@ -17,6 +19,8 @@ x1, y1, x2, y2 = (np.tile(np.concatenate([p[k] for p in parts]), n // 50) for k 
 b = HomographyBatch(off, x1, y1, x2, y2)
 params = dict(max_error=2.0)
 b.ransac(seed=1, params=params)
+for _ in range(4):
+    t = time.perf_counter(); b.ransac(seed=1, params=params); print("  one call %.3f ms" % (1e3 * (time.perf_counter() - t)))
 for trials in (100, 25):
     params["max_num_trials"] = trials
     t = time.perf_counter()
