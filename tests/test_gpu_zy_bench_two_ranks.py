@@ -62,3 +62,38 @@ def test_two_rank_bench_line_weak_scaling():
     assert abs(d["value"] - 2 * 1080000 * 4 / (d["ms_per_step"] * 4 * 1e-3)) <= 1e-6 * d["value"]
     assert d["config5_strong"]["observations"] == 10800000      # config 5 is cut over the ranks in either mode
     assert "config4_weak" not in d                              # it is the headline here
+
+
+def test_bench_exchange_hook_on_rccl_with_one_rank():
+    """the hook bench.py hands the library for N > 1 (a device buffer wrapped as a torch tensor, reduced by
+    torch.distributed on the stream the library names) on the REAL backend -- "nccl" = RCCL -- as far as one GPU allows:
+    a world of one rank.  What it pins: RCCL initialises in this process, the external stream and the foreign pointer are
+    accepted, the sum lands in place (x1 with one rank), work enqueued behind it on that stream sees it."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    code = r"""
+import ctypes as C, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bench
+from cvx_amd import capi
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+hook = bench.make_hook(torch, dist, capi)
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    t = torch.arange(1000, dtype=torch.float64, device="cuda") * 0.5
+    rc = hook(None, C.cast(t.data_ptr(), C.POINTER(C.c_double)), t.numel(), 1, C.c_void_p(st.cuda_stream))
+    u = t * 2.0                      # behind the collective on the same stream
+st.synchronize()
+assert rc == 0
+assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64) * 0.5) and torch.equal(u.cpu(), torch.arange(1000, dtype=torch.float64))
+host = np.arange(16, dtype=np.float64)
+rc = hook(None, host.ctypes.data_as(C.POINTER(C.c_double)), host.size, 0, None)
+assert rc == 0 and host.tolist() == list(range(16))
+dist.destroy_process_group()
+print("hook ok")
+""" % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=200)
+    assert p.returncode == 0 and "hook ok" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
