@@ -392,16 +392,18 @@ void homography_solve_ransac_batch(const std::vector<const std::vector<Point> *>
             const int N = off[i + 1] - off[i];
             if (N < 4) continue;                                   // assert(N <= n), ransac.hpp:32
             vidx.resize((size_t)N);
+            for (int k = 0; k < N; ++k) vidx[(size_t)k] = k;           // rng.hpp:66-67, made once: the swaps are undone below
             for (size_t t = 0; t < T; ++t) {
-                for (int k = 0; k < N; ++k) vidx[(size_t)k] = k;
-                int max_idx = N - 1;
+                int max_idx = N - 1, drawn[4];
                 for (int k = 0; k < 4; ++k) {
                     std::uniform_int_distribution<> ud(0, max_idx);
                     const int index = ud(generator);
                     std::swap(vidx[(size_t)index], vidx[(size_t)max_idx]);
                     subsets[(i * T + t) * 4 + (size_t)k] = vidx[(size_t)max_idx];
+                    drawn[k] = index;
                     --max_idx;
                 }
+                for (int k = 3; k >= 0; --k) std::swap(vidx[(size_t)drawn[k]], vidx[(size_t)(N - 1 - k)]);   // back to 0 .. N-1
             }
         }
     }
