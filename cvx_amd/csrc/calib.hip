@@ -209,7 +209,8 @@ struct cvx_calib {
     double *d_ib_ptslab = nullptr, *d_pt_ox = nullptr, *d_pt_oy = nullptr;
     int *d_pt_view = nullptr, *d_pt_cam = nullptr;
     int pt_slices = 1;               // workgroups per point block
-    double *h_ib_active = nullptr;   // pinned: [0] blocks that go on, [1..2] step norm parts
+    double *h_ib_active = nullptr;   // pinned: [0] blocks that go on, [1..2] step norm parts, [4..5] the polled count and its sequence number
+    long long ib_seq = 0;
     // the host half of the first use (ordering, the points' observation lists), possibly made ahead on a host thread
     struct InnerHostPrep {
         int status = CVX_OK, sets = 0;
@@ -767,6 +768,25 @@ int inner_pass(cvx_calib *h, int which, int *rank_local_status) {
             if (shared && sharded) {        // leave the set together (a set of pose blocks only has nothing to agree on)
                 st = exchange_sum(h, h->d_ib_active, 1);
                 if (st) return st;
+            }
+            if (h->d_E2_map && !h->timing && !(shared && sharded)) {
+                // the count goes to host-mapped memory behind the round's last kernel; the host polls its sequence number
+                double *slot = h->d_E2_map + (h->h_ib_active - h->h_E2) + 4;
+                const double want = (double)++h->ib_seq;
+                hipLaunchKernelGGL(cvxi::k_inner_publish, dim3(1), t64, 0, h->stream, h->d_ib_active, slot, want);
+                CVX_HIP(hipGetLastError());
+                volatile const double *flag = h->h_ib_active + 5;
+                const auto t0 = std::chrono::steady_clock::now();
+                long long spins = 0;
+                while (*flag != want) {
+                    if ((++spins & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+                        CVX_HIP(hipStreamSynchronize(h->stream));       // surfaces a kernel fault as a HIP error
+                        if (*flag != want) { cvx::set_last_error("inner iterations: a round's count never arrived in host memory"); return CVX_ERR_HIP; }
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (h->h_ib_active[4] == 0.0) break;
+                continue;
             }
             CVX_HIP(hipMemcpyAsync(h->h_ib_active, h->d_ib_active, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             CVX_HIP(hipStreamSynchronize(h->stream));
@@ -1386,6 +1406,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
         double *q = h->h_E2 + 64;
         h->h_lm = reinterpret_cast<LmDev *>(q); q += up8(n_lm);
         h->h_ib_active = q; q += 8;
+        std::memset(h->h_ib_active, 0, 8 * sizeof(double));     // [5] is a polled sequence number
         h->h_ds_emb = q; q += up8(n_emb);
         h->h_params = q; q += up8(std::max<size_t>(n_par, 1));
         h->h_E_res = q;

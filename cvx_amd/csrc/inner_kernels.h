@@ -461,6 +461,16 @@ __global__ void __launch_bounds__(64) k_inner_decide(InnerArgs a) {
     atomicAdd(a.active, 1.0);           // integers in a double: exact in any order
 }
 
+// the round's count of blocks that go on, into host-mapped memory behind k_inner_decide: the host polls the sequence number
+// instead of waiting for a copy (a stream synchronisation wakes up 10-20 us after the fact, and a pass has six of them)
+__global__ void __launch_bounds__(64) k_inner_publish(const double *active, double *host, double seq) {
+    if (threadIdx.x != 0) return;
+    host[0] = *active;
+    __threadfence_system();
+    host[1] = seq;
+    __threadfence_system();
+}
+
 // View-sharded runs: a shared block's sums are partial on every rank.  DIR 0 lays the rows of the running blocks
 // (zeros for all others) into the exchange buffer X, DIR 1 takes the all-reduced rows back.  The LM state of a
 // shared block is replicated -- every rank takes the same decisions from the same sums -- so "running" is the same
