@@ -5,6 +5,8 @@
 // the 6x6 pose system and runs the trust-region loop of lm_driver.cpp with the options of :201-210.
 #include <algorithm>
 #include <cmath>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -25,6 +27,8 @@ struct cvx_toolba {
     int *d_view = nullptr, *d_jobs = nullptr, *d_job_first = nullptr;
     double *d_trans = nullptr, *d_params = nullptr, *d_intr = nullptr, *d_partial = nullptr, *d_cpartial = nullptr, *d_out = nullptr;
     double *h_out = nullptr, *h_params = nullptr;
+    double *d_out_map = nullptr;     // device view of h_out (host-mapped): results are written there and polled for
+    long long seq = 0;
     // exchange (view-sharded runs: every rank holds its own views' observations, the pose and the points are shared)
     cvx_allreduce_fn xfn = nullptr;
     void *xctx = nullptr;
@@ -56,6 +60,32 @@ int upload(cvx_toolba *h, const double *x) {
     return CVX_OK;
 }
 
+// d_out[first .. first + cnt) -> h_out, and wait for it: written into host-mapped memory by a kernel behind the ones that
+// made it and polled for (toolba_kernels.h: k_tba_publish); without a device view of h_out, a copy and a synchronisation
+int fetch(cvx_toolba *h, size_t first, size_t cnt) {
+    if (!h->d_out_map) {
+        CVX_HIP(hipMemcpyAsync(h->h_out + first, h->d_out + first, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+        CVX_HIP(hipStreamSynchronize(h->stream));
+        return CVX_OK;
+    }
+    const size_t flag_at = (size_t)h->P * TBA_ACC + 4;
+    const double want = (double)++h->seq;
+    hipLaunchKernelGGL(k_tba_publish, dim3(1), dim3(256), 0, h->stream, h->d_out + first, h->d_out_map + first, (long long)cnt,
+                       h->d_out_map + flag_at, want);
+    CVX_HIP(hipGetLastError());
+    volatile const double *flag = h->h_out + flag_at;
+    const auto t0 = std::chrono::steady_clock::now();
+    long long spins = 0;
+    while (*flag != want) {
+        if ((++spins & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) {
+            CVX_HIP(hipStreamSynchronize(h->stream));       // surfaces a kernel fault as a HIP error
+            if (*flag != want) { cvx::set_last_error("tool bundle adjustment: a result never arrived in host memory"); return CVX_ERR_HIP; }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return CVX_OK;
+}
+
 // 1/2 sum rho at x
 int device_cost(cvx_toolba *h, const double *x, double *cost) {
     int st = upload(h, x);
@@ -72,8 +102,8 @@ int device_cost(cvx_toolba *h, const double *x, double *cost) {
     CVX_HIP(hipGetLastError());
     const bool sharded = h->nranks > 1 && h->xfn;
     if (sharded && h->xdev && h->xfn(h->xctx, h->d_out + slot, 1, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
-    CVX_HIP(hipMemcpyAsync(h->h_out + slot, h->d_out + slot, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    CVX_HIP(hipStreamSynchronize(h->stream));
+    int fst = fetch(h, slot, 1);
+    if (fst) return fst;
     if (sharded && !h->xdev && h->xfn(h->xctx, h->h_out + slot, 1, 0, nullptr)) return CVX_ERR_EXCHANGE;
     *cost = 0.5 * h->h_out[slot];
     return CVX_OK;
@@ -94,8 +124,8 @@ int device_blocks(cvx_toolba *h, const double *x) {
     const size_t cnt = TBA_ACC * (size_t)h->P;
     const bool sharded = h->nranks > 1 && h->xfn;
     if (sharded && h->xdev && h->xfn(h->xctx, h->d_out, cnt, 1, (void *)h->stream)) return CVX_ERR_EXCHANGE;
-    CVX_HIP(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
-    CVX_HIP(hipStreamSynchronize(h->stream));
+    int fst = fetch(h, 0, cnt);
+    if (fst) return fst;
     if (sharded && !h->xdev && h->xfn(h->xctx, h->h_out, cnt, 0, nullptr)) return CVX_ERR_EXCHANGE;
     return CVX_OK;
 }
@@ -547,8 +577,10 @@ extern "C" int cvx_toolba_create(const cvx_toolba_desc *d, cvx_toolba **out) {
         void **slots[10] = {(void **)&h->d_obs, (void **)&h->d_view, (void **)&h->d_jobs, (void **)&h->d_job_first, (void **)&h->d_trans,
                             (void **)&h->d_params, (void **)&h->d_intr, (void **)&h->d_partial, (void **)&h->d_cpartial, (void **)&h->d_out};
         for (int k = 0; k < 10; ++k) { *slots[k] = base; base += up(sizes[k]); }
-        CVX_HIP(hipHostMalloc((void **)&h->h_out, (n_out + n_par) * sizeof(double), hipHostMallocDefault));
+        CVX_HIP(hipHostMalloc((void **)&h->h_out, (n_out + n_par) * sizeof(double), hipHostMallocMapped));
         h->h_params = h->h_out + n_out;
+        std::memset(h->h_out + (size_t)P * TBA_ACC, 0, 8 * sizeof(double));     // [4] is a polled sequence number
+        if (hipHostGetDevicePointer((void **)&h->d_out_map, h->h_out, 0) != hipSuccess) { (void)hipGetLastError(); h->d_out_map = nullptr; }
     }
     CVX_HIP(hipMemcpyAsync(h->d_obs, obs.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_view, view.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));

@@ -245,6 +245,19 @@ __global__ __launch_bounds__(TBA_THREADS) void k_tba_cost(TbaArgs a) {
 }
 
 // one workgroup: out[0] = sum of the chunk costs in a fixed order
+// What the host reads after a linearisation (the P x 55 block sums) or a cost evaluation (one double), written into its
+// host-mapped copy behind the kernels that made it, then a sequence number the host polls: a copy and a stream
+// synchronisation wake the host up 10-20 us after the fact, twice per LM iteration of 95 us.
+__global__ __launch_bounds__(256) void k_tba_publish(const double *src, double *dst, long long n, double *flag, double seq) {
+    for (long long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *flag = seq;
+        __threadfence_system();
+    }
+}
+
 __global__ __launch_bounds__(TBA_THREADS) void k_tba_cost_final(const double *partial, int n, double *out) {
     __shared__ double red[TBA_THREADS / 64];
     double c = 0.0;
