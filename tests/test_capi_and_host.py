@@ -261,3 +261,21 @@ def test_schur_task_list_covers_every_block_and_every_stage_row_once():
     assert [r["nb"] for r in rows] == list(range(1, 26))
     assert all(r["blocks_wrong"] == 0 and r["copy_wrong"] == 0 and r["diag_copies"] == 0 for r in rows)
     assert {r["nb"]: r["parts"] for r in rows}[21] == 2      # config 4: 15 tasks on 2 x 8 waves
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/cvx_amd.h compiles as C99 with -pedantic, no C++ needed to bind it"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "cvx_amd.h"\nint main(void) { cvx_ransac_params p; cvx_ransac_default_params(&p); '
+                   'cvx_lm_options o; cvx_lm_options_refine(&o); return p.max_num_trials + o.max_iterations > 0 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_ransac_defaults_are_the_reference_parameters():
+    p = capi.RansacParams()
+    capi.lib().cvx_ransac_default_params(C.byref(p))
+    assert (p.max_error, p.outlier_probability, p.max_num_trials, p.min_inliers) == (0.1, 0.1, 100, 5)     # ransac.hpp:14-22
+
