@@ -57,6 +57,41 @@ int main(int argc, char **argv) {
         if (rep >= 2) { t_d += a; t_c += b; t_f += c; }
     }
     printf("n=%d nT=%d  damp %.1f us  chol %.1f us (%.1f/step)  finish %.1f us\n", n, nT, 1e3 * t_d / reps, 1e3 * t_c / reps, 1e3 * t_c / reps / nT, 1e3 * t_f / reps);
+    {
+        // the same chain (damp, nT tile columns, finish) as ONE linear hipGraph, captured from a stream: what the graph
+        // saves is the host's launches, which the LM loop hides behind the device's work; the gaps between dependent kernels
+        // are the device's own and stay
+        hipStream_t st;
+        CK(hipStreamCreate(&st));
+        hipGraph_t graph; hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        hipLaunchKernelGGL(cvxs::k_damp_prepare, dim3((npad * npad + 255) / 256), dim3(256), 0, st, da);
+        for (int k = 0; k < nT; ++k)
+            hipLaunchKernelGGL(cvxs::k_chol_step, dim3(cvxs::chol_step_blocks(nT, k)), dim3(256), 0, st, dA, npad, n, k, nT, dfail, ddelta);
+        hipLaunchKernelGGL(cvxs::k_step_finish, dim3(1), dim3(cvxs::FIN_THREADS), lds, st, f);
+        CK(hipStreamEndCapture(st, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        float tg = 0, te = 0;
+        for (int rep = 0; rep < reps + 2; ++rep) {
+            CK(hipEventRecord(ev[0], st));
+            CK(hipGraphLaunch(exec, st));
+            CK(hipEventRecord(ev[1], st));
+            CK(hipStreamSynchronize(st));
+            float a; CK(hipEventElapsedTime(&a, ev[0], ev[1]));
+            if (rep >= 2) tg += a;
+            CK(hipEventRecord(ev[0], st));
+            hipLaunchKernelGGL(cvxs::k_damp_prepare, dim3((npad * npad + 255) / 256), dim3(256), 0, st, da);
+            for (int k = 0; k < nT; ++k)
+                hipLaunchKernelGGL(cvxs::k_chol_step, dim3(cvxs::chol_step_blocks(nT, k)), dim3(256), 0, st, dA, npad, n, k, nT, dfail, ddelta);
+            hipLaunchKernelGGL(cvxs::k_step_finish, dim3(1), dim3(cvxs::FIN_THREADS), lds, st, f);
+            CK(hipEventRecord(ev[1], st));
+            CK(hipStreamSynchronize(st));
+            CK(hipEventElapsedTime(&a, ev[0], ev[1]));
+            if (rep >= 2) te += a;
+        }
+        printf("damp + %d tile columns + finish: as a hipGraph %.1f us, as %d launches on a stream %.1f us\n", nT, 1e3 * tg / reps, nT + 2, 1e3 * te / reps);
+        CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph)); CK(hipStreamDestroy(st));
+    }
 #ifdef CVX_STAMPS
     { long long cs[64]; CK(hipMemcpyFromSymbol(cs, HIP_SYMBOL(cvxs::g_cstamps), sizeof cs));
       printf("chol step 3: load %lld  factor %lld  tail %lld ns\n", (cs[1]-cs[0])*10, (cs[2]-cs[1])*10, (cs[3]-cs[2])*10); }
