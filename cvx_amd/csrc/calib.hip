@@ -185,6 +185,8 @@ struct cvx_calib {
     double *d_ds_emb = nullptr, *h_ds_emb = nullptr, *d_dposes = nullptr, *d_out_view = nullptr;
     double *d_cost_partial = nullptr, *d_E2 = nullptr, *h_E2 = nullptr;
     hipEvent_t ev_step = nullptr;
+    hipEvent_t ev_params = nullptr;  // behind set_params' copies out of h_params: the next writer of the staging block waits for it
+    bool params_pending = false;
     double *d_E2_map = nullptr;      // device view of h_E2 (host-mapped, fine-grained)
     long long step_seq = 0;
     double *d_eval = nullptr;
@@ -281,6 +283,7 @@ cvx_calib::~cvx_calib() {
     if (ev_made)
         for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(ev[i][0]); (void)hipEventDestroy(ev[i][1]); }
     if (ev_step) (void)hipEventDestroy(ev_step);
+    if (ev_params) (void)hipEventDestroy(ev_params);
     if (own_stream && stream) {
         if (idle) cvx::stream_give(device, stream);
         else (void)hipStreamDestroy(stream);
@@ -1421,6 +1424,7 @@ extern "C" int cvx_calib_create(const cvx_calib_desc *d, cvx_calib **out) {
     h->n_cost_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (h->N + 255) / 256));
     CVX_TRY(h->dalloc(&h->d_cost_partial, (size_t)h->n_cost_blocks));
     CVX_HIP(hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming));
+    CVX_HIP(hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
     CVX_TRY(h->dalloc(&h->d_E2, 16));
     CVX_HIP(hipMemsetAsync(h->d_E2, 0, 16 * sizeof(double), s));
     // two records of 32 doubles (a speculated step may publish while the host still reads the one before)
@@ -1490,17 +1494,20 @@ extern "C" int cvx_calib_set_params(cvx_calib *h, const double *intr, const doub
     CVX_HIP(hipSetDevice(h->device));
     const int c = h->cur;
     h->rt_valid[c] = false;
-    // through the handle's pinned staging block: three asynchronous copies and one wait (copies from pageable memory wait
-    // one by one)
+    // through the handle's pinned staging block: three asynchronous copies (copies from pageable memory wait one by one)
+    // and NO wait -- whatever uses the parameters next is on the same stream; only the next writer of the staging block
+    // has to know that the copies are through, and asks the event
     double *sp = h->h_params;
     const size_t ni = 9 * (size_t)h->C, np = 3 * (size_t)h->P, nv = 6 * (size_t)h->V;
+    if (h->params_pending) { CVX_HIP(hipEventSynchronize(h->ev_params)); h->params_pending = false; }
     std::memcpy(sp, intr, sizeof(double) * ni);
     std::memcpy(sp + ni, points, sizeof(double) * np);
     if (nv) std::memcpy(sp + ni + np, poses, sizeof(double) * nv);
     CVX_HIP(hipMemcpyAsync(h->d_intr[c], sp, sizeof(double) * ni, hipMemcpyHostToDevice, h->stream));
     CVX_HIP(hipMemcpyAsync(h->d_points[c], sp + ni, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
     if (nv) CVX_HIP(hipMemcpyAsync(h->d_poses[c], sp + ni + np, sizeof(double) * nv, hipMemcpyHostToDevice, h->stream));
-    CVX_HIP(hipStreamSynchronize(h->stream));
+    CVX_HIP(hipEventRecord(h->ev_params, h->stream));
+    h->params_pending = true;
     return CVX_OK;
 }
 
@@ -1513,7 +1520,8 @@ extern "C" int cvx_calib_get_params(cvx_calib *h, double *intr, double *poses, d
     if (intr) CVX_HIP(hipMemcpyAsync(sp, h->d_intr[c], sizeof(double) * ni, hipMemcpyDeviceToHost, h->stream));
     if (points) CVX_HIP(hipMemcpyAsync(sp + ni, h->d_points[c], sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
     if (poses && nv) CVX_HIP(hipMemcpyAsync(sp + ni + np, h->d_poses[c], sizeof(double) * nv, hipMemcpyDeviceToHost, h->stream));
-    CVX_HIP(hipStreamSynchronize(h->stream));
+    CVX_HIP(hipStreamSynchronize(h->stream));       // (set_params' copies out of the block are ahead of these on the stream)
+    h->params_pending = false;
     if (intr) std::memcpy(intr, sp, sizeof(double) * ni);
     if (points) std::memcpy(points, sp + ni, sizeof(double) * np);
     if (poses && nv) std::memcpy(poses, sp + ni + np, sizeof(double) * nv);

@@ -163,7 +163,9 @@ void cvx_calib_destroy(cvx_calib *h);
 
 /* parameter blocks in the reference's layouts: intrinsics[n_cameras][9] in the order
  * fx,fy,cx,cy,k1,k2,k3,p1,p2 (calibration.cpp:219-229); poses[n_views][6] = angle-axis, t
- * (calibration.cpp:318-332); points[n_points][3] */
+ * (calibration.cpp:318-332); points[n_points][3].  set_params returns once the caller's arrays have been copied into
+ * the handle's pinned staging block (they may be freed or changed at once); the upload itself is ordered on the
+ * handle's stream ahead of whatever the handle does next. */
 int cvx_calib_set_params(cvx_calib *h, const double *intrinsics, const double *poses, const double *points);
 int cvx_calib_get_params(cvx_calib *h, double *intrinsics, double *poses, double *points);
 
