@@ -187,6 +187,58 @@ def test_two_rank_solve_equals_single_rank():
         assert np.max(np.abs(np.array(a["p"]) - pt)) <= 1e-8 and np.max(np.abs(np.array(a["x"]) - xt)) <= 1e-8
 
 
+def _one_camera_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cvx_amd
+    from cvx_amd import capi
+    import bench
+    d = cvx_amd.synth_calib(world, 6, 12, 9, 78)                # dense: the cut by observations falls between the cameras
+    first = cvx_amd.partition_views(d["view_off"], world)
+    sh = cvx_amd.shard_calib(d, first, rank)
+    assert set(sh["cam_of_view"].tolist()) == {rank}            # this rank sees ONE camera of `world`
+    g = cvx_amd.Calib(sh["cam_of_view"], sh["view_off"], sh["point_id"], sh["obs_x"], sh["obs_y"], d["C"], d["P"])
+    g.set_exchange(bench.make_hook(torch, dist, capi), rank, world, device_buffers=True)
+    g.set_params(d["intr_init"], sh["poses_init"], d["points_init"])
+    s = g.solve(capi.options("refine"))
+    intr, poses, pts = g.get_params()
+    out[rank] = {"it": s.iterations, "term": s.termination, "cost": s.final_cost, "trace": s.trace()["cost"].tolist(),
+                 "passes": s.num_inner_iteration_steps, "intr": intr.tolist(), "pts": pts.tolist(), "poses": poses.tolist()}
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_one_camera_each_equal_single_rank():
+    """the shape an 8-GPU run of config 4 has (8 cameras x 1250 views over 8 ranks: every rank holds the views of exactly one
+    camera, the other cameras' blocks have no local residuals), at world 4 on this one GPU: the reference's options with
+    their inner iterations, device-buffer protocol, against the single-rank solve"""
+    import cvx_amd
+    from cvx_amd import capi
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_helpers import assert_params_close
+    world = 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_camera_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    d = cvx_amd.synth_calib(world, 6, 12, 9, 78)
+    g = cvx_amd.Calib(d["cam_of_view"], d["view_off"], d["point_id"], d["obs_x"], d["obs_y"], d["C"], d["P"])
+    g.set_params(d["intr_init"], d["poses_init"], d["points_init"])
+    s = g.solve(capi.options("refine"))
+    ref = g.get_params()
+    g.close()
+    r = [out[k] for k in range(world)]
+    for k in range(1, world):
+        assert r[k]["intr"] == r[0]["intr"] and r[k]["pts"] == r[0]["pts"] and r[k]["trace"] == r[0]["trace"]
+    assert (r[0]["it"], r[0]["term"], r[0]["passes"]) == (s.iterations, s.termination, s.num_inner_iteration_steps)
+    tr = np.array(r[0]["trace"])
+    assert np.all(np.abs(tr - s.trace()["cost"]) <= 1e-10 * tr)
+    assert abs(r[0]["cost"] - s.final_cost) <= 1e-11 * s.final_cost
+    got = (np.array(r[0]["intr"]), np.concatenate([np.array(x["poses"]) for x in r]), np.array(r[0]["pts"]))
+    assert_params_close(got, ref, None, "four ranks, one camera each")
+
+
 def _rccl_worker(rank, world, port, out):
     """one process per GPU: the built-in RCCL hook (cvx_rccl_*) under a view-sharded solve"""
     sys.path.insert(0, ROOT)
