@@ -375,15 +375,23 @@ void homography_solve_ransac_batch(const std::vector<const std::vector<Point> *>
                                    const std::vector<const std::vector<Point> *> &pts2, std::vector<Mat3> &H,
                                    std::vector<std::vector<size_t>> &inliers, std::vector<char> &ok,
                                    const ransac_parameters &params = ransac_parameters(), const uint64_t *rng_seed = nullptr,
-                                   int refine_iterations = 0, int device = 0, void *stream = nullptr) {
+                                   int refine_iterations = 0, int device = 0, void *stream = nullptr,
+                                   bool draw_on_device = false) {
+    // draw_on_device: the subsets come from the library's own counter-based generator on the device (seeded with
+    // *rng_seed, or from std::random_device) instead of std::mt19937_64 here -- for large batches, where four million
+    // draws on one host core and their upload cost twenty times the device's whole run; RNG::sample's law, another stream
     const size_t n = pts1.size();
     H.resize(n); inliers.assign(n, std::vector<size_t>()); ok.assign(n, 0);
     if (n == 0) return;
     std::vector<int> off;
     cvx_homography *hh = detail::homography_handle(pts1, pts2, off, device, stream);
     const size_t T = params.max_num_trials_;
-    std::vector<int> subsets(n * T * 4, 0);
-    {
+    std::vector<int> subsets(draw_on_device ? 0 : n * T * 4, 0);
+    uint64_t device_seed = 0;
+    if (draw_on_device) {
+        if (rng_seed) device_seed = *rng_seed;
+        else { std::random_device rd; device_seed = ((uint64_t)rd() << 32) ^ rd(); }
+    } else {
         std::mt19937_64 generator;
         if (rng_seed) generator.seed(*rng_seed);
         else { std::random_device rd; generator.seed(rd()); }
@@ -414,8 +422,8 @@ void homography_solve_ransac_batch(const std::vector<const std::vector<Point> *>
     std::vector<int> cnt(n, 0);
     std::vector<unsigned char> mask((size_t)(off[n] > 0 ? off[n] : 1), 0);
     cvx_homography *nb = nullptr;
-    int st = cvx_homography_ransac(hh, &p, subsets.data(), 0, h.data(), cnt.data(), mask.data(), nullptr, nullptr,
-                                   refine_iterations > 0 ? &nb : nullptr);
+    int st = cvx_homography_ransac(hh, &p, draw_on_device ? nullptr : subsets.data(), device_seed, h.data(), cnt.data(), mask.data(),
+                                   nullptr, nullptr, refine_iterations > 0 ? &nb : nullptr);
     if (!st && nb) {
         st = cvx_homography_run(nb, refine_iterations, nullptr);
         if (!st) st = cvx_homography_get(nb, h.data(), nullptr, nullptr);

@@ -175,6 +175,19 @@ int main() {
             std::fprintf(stderr, "%s\n", e.what());
             return 10;
         }
+        // and with the subsets drawn on the device
+        std::vector<Mat3> Hd2;
+        std::vector<std::vector<size_t>> ind2;
+        std::vector<char> okd2;
+        try {
+            cvx_amd::homography_solve_ransac_batch<Pt2f, Mat3>({&b1}, {&c2}, Hd2, ind2, okd2, rp, &seed, 0, 0, nullptr, true);
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return 11;
+        }
+        std::printf("\"ransac_dev_ok\": %d, \"ransac_dev_inliers\": [", (int)okd2[0]);
+        for (size_t i = 0; i < ind2[0].size(); ++i) std::printf("%s%zu", i ? ", " : "", ind2[0][i]);
+        std::printf("], ");
         std::printf("\"ransac_lm_ok\": [%d, %d], \"ransac_lm_H\": [", (int)okb[0], (int)okb[1]);
         for (int i = 0; i < 9; ++i) std::printf("%s%.17g", i ? ", " : "", Hb[0].m[i]);
         std::printf("], \"ransac_lm_inliers\": [");

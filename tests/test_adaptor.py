@@ -89,6 +89,8 @@ def test_adaptor_refine_and_handeye_match_oracle(orc):
     c2[::7] += 40; e2[::7] -= 25
     rr, Hr = orc.homography_dlt(a1[inl], b1[inl], c2[inl], e2[inl])
     assert rr > 0 and np.max(np.abs(np.array(out["ransac_H0"]) - Hr)) <= 1e-11 * np.max(np.abs(Hr))
+    devin = set(out["ransac_dev_inliers"])                  # subsets drawn on the device: a model, none of the planted outliers
+    assert out["ransac_dev_ok"] == 1 and len(devin) > 5 and not devin & set(range(0, o1 - o0, 7))
     # the batch form with refine_iterations: view 0 draws the same first hundred subsets as the single call (same seed), so
     # the same inliers and refit; then solveLM over them, bit for bit the oracle's LM from that refit
     assert out["ransac_lm_ok"] == [1, 1] and out["ransac_lm_inliers"] == out["ransac_inliers0"]
